@@ -1,0 +1,106 @@
+"""ctypes binding of libbrepgen_hip.so -- the C ABI declared in include/brepgen_hip.h.
+
+There is NO fallback: if the library is missing the import of any compute entry point raises.  The product
+path never touches ``oracle/`` or torch math for the work the HIP kernels do.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbrepgen_hip.so")
+
+BG_F32, BG_F16, BG_BF16 = 0, 1, 2
+BG_ACT_NONE, BG_ACT_RELU = 0, 1
+BG_SURFPOS, BG_SURFZ, BG_EDGEPOS, BG_EDGEZ = 0, 1, 2, 3
+BG_MAX_LAYERS, BG_MAX_EMBEDS = 12, 5
+
+vp, fp, i64p, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device pointers travel as integers
+
+
+class MlpWeights(C.Structure):
+    _fields_ = [("w0", vp), ("b0", fp), ("ln_g", fp), ("ln_b", fp), ("w3", vp), ("b3", fp),
+                ("k_in", C.c_int), ("n_out", C.c_int), ("n_out_pad", C.c_int), ("w0_dtype", C.c_int)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("ln1_g", fp), ("ln1_b", fp), ("ln2_g", fp), ("ln2_b", fp),
+                ("w_qkv", vp), ("b_qkv", fp), ("w_o", vp), ("b_o", fp),
+                ("w_1", vp), ("b_1", fp), ("w_2", vp), ("b_2", fp)]
+
+
+class DenoiserWeights(C.Structure):
+    _fields_ = [("net", C.c_int), ("dtype", C.c_int), ("n_layer", C.c_int), ("_pad", C.c_int),
+                ("layers", LayerWeights * BG_MAX_LAYERS),
+                ("lnf_g", fp), ("lnf_b", fp),
+                ("time_embed", MlpWeights), ("fc_out", MlpWeights),
+                ("embed", MlpWeights * BG_MAX_EMBEDS),
+                ("class_embed", fp)]
+
+
+class DenoiserInputs(C.Structure):
+    _fields_ = [("B", C.c_int), ("S", C.c_int), ("E", C.c_int), ("n_timesteps", C.c_int),
+                ("x", fp), ("surf_pos", fp), ("surf_z", fp), ("edge_pos", fp), ("mask", u8p),
+                ("timesteps", i64p), ("class_label", i64p), ("cond_cache", fp),
+                ("cond_cache_valid", C.c_int), ("_pad", C.c_int)]
+
+
+_SIGNATURES = {
+    "bg_abi_version": (C.c_int, []),
+    "bg_last_error": (C.c_char_p, []),
+    "bg_sincos_embed": (C.c_int, [i64p, C.c_int, fp, vp]),
+    "bg_layernorm_fwd": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
+    "bg_gemm_bias_act_fwd": (C.c_int, [vp, C.c_int, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, vp]),
+    "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bg_denoiser_fwd": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenoiserInputs), fp, vp, C.c_size_t, vp]),
+    "bg_cfg_ddpm_step": (C.c_int, [fp, fp, C.c_float, fp, fp, fp, C.c_size_t] + [C.c_float] * 6 + [vp]),
+    "bg_pndm_step": (C.c_int, [fp, fp, C.c_float, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
+                               fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp,
+                               C.c_size_t, vp]),
+    "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class BrepgenHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (once).  Raises if it has not been built: no silent CPU/torch fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BrepgenHipError(
+                f"{LIB_PATH} is missing -- build it with `python -m brepgen_amd.build` "
+                "(hipcc --offload-arch=gfx950); brepgen_amd has no fallback path")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export the ABI
+            fn.restype, fn.argtypes = res, args
+        if lib.bg_abi_version() != 1:
+            raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().bg_last_error().decode(errors="replace")
+        raise BrepgenHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host, for CPU-side tests of argument checking) address of a contiguous tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libbrepgen_hip takes dense row-major tensors"
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

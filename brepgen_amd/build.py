@@ -1,0 +1,72 @@
+"""Build libbrepgen_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: plain `hipcc -c` per kernel
+file (in parallel) and one link.  The .so is git-ignored but travels to the GPU box with the repo snapshot.
+
+    python -m brepgen_amd.build [--force] [--save-temps]
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libbrepgen_hip.so")
+SOURCES = ["elementwise.hip", "gemm_f32.hip", "gemm_bf16.hip", "attn.hip", "denoiser.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libbrepgen_hip.so cannot be built")
+    return exe
+
+
+def _digest():
+    h = hashlib.sha256()
+    files = sorted(os.listdir(CSRC)) + ["../../include/brepgen_hip.h"]
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src, extra):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return obj, r.stderr
+
+
+def build(force=False, save_temps=False, verbose=True):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
+    os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, "digest.txt")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    extra = ["-save-temps"] if save_temps else []
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        results = list(ex.map(lambda s: _compile(s, extra), SOURCES))
+    for _, warn in results:
+        if verbose and warn.strip():
+            sys.stderr.write(warn)
+    objs = [o for o, _ in results]
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+    print(path)

@@ -1,0 +1,264 @@
+// Masked multi-head self-attention of the denoisers (12 heads x 64, scale 1/8 folded into q by the weight
+// packer, additive -inf key-padding mask; network.py:1076-1078 -> torch MHA slow path -> SDPA).
+//
+// bf16 kernel (MFMA, flash-style online softmax; any N):
+//   * one workgroup = 4 waves = one sample b, 4/WPH heads, WPH*32 queries per head; each wave owns 32 queries
+//     of one head and walks the keys in tiles of 64;
+//   * scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16 with A = K rows from LDS, B = Q rows
+//     held in registers), so every lane holds 16 keys of ONE query: the softmax row reductions are in-lane plus a
+//     single lane <-> lane+32 exchange, and the running max / sum / rescale factors are lane-local to the O^T
+//     accumulator columns as well;
+//   * P^T is fed straight back as the B operand of O^T = V^T P^T: the k-slot order of the MFMA is a free
+//     permutation as long as both operands agree, so the A operand (V^T rows from LDS) is simply read in the key
+//     order the lane's score registers already have (two 8-byte reads) -- no cross-lane shuffle of P at all;
+//   * K tile in LDS: 64 keys x 128 B, LDS-DMA + 16-byte XOR swizzle (same scheme as the GEMM);
+//     V tile in LDS: transposed [64 d][64 keys], row stride 68 bf16 so the 32 d-rows a half-wave reads with
+//     ds_read_b64 fall on 32 distinct bank pairs.
+// fp32 kernel: exact VALU restatement for the fp32 parity mode (not a performance path).
+#include "bg_common.h"
+#include <math.h>
+
+namespace bg {
+
+constexpr int QKV_LD = 3 * BG_D_MODEL;     // 2304
+constexpr int VS = 68;                     // V^T row stride (bf16 elements)
+constexpr int HEAD_LDS = 64 * 128 + 64 * VS * 2;   // K tile + V^T tile bytes per head slot = 16896
+
+template <int WPH>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const __bf16* __restrict__ qkv,
+                                                        const uint8_t* __restrict__ key_pad,
+                                                        __bf16* __restrict__ out, int B, int N) {
+    constexpr int HPW = 4 / WPH;               // heads per workgroup
+    constexpr int KPI = 8 / WPH;               // K-tile DMA instructions per wave
+    __shared__ __attribute__((aligned(16))) unsigned char lds[HPW * HEAD_LDS + 256];
+    float* mb = reinterpret_cast<float*>(lds + HPW * HEAD_LDS);   // additive mask bias of the 64 keys of a tile
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hl = wave / WPH, qt = wave % WPH;
+    const int b = blockIdx.z;
+    const int head = blockIdx.y * HPW + hl;
+    const int q0 = (blockIdx.x * WPH + qt) * 32;
+    unsigned char* ktile = lds + hl * HEAD_LDS;
+    __bf16* vt = reinterpret_cast<__bf16*>(ktile + 64 * 128);
+    const __bf16* base = qkv + (size_t)b * N * QKV_LD + head * 64;
+
+    // Q fragments (B operand of S^T = K Q^T): lane = (query l&31, k-chunk h) for each 16-wide slice of d
+    bf16x8 qf[4];
+    {
+        int qrow = q0 + (lane & 31);
+        qrow = qrow < N ? qrow : N - 1;
+        const __bf16* qp = base + (size_t)qrow * QKV_LD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (ks * 2 + h) * 8);
+    }
+    // K fragment read offsets (A operand): key row l&31 (+32 for the second sub-tile)
+    int k_off[2], k_sw[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int row = sub * 32 + (lane & 31);
+        k_off[sub] = row * 128;
+        k_sw[sub] = (row >> 1) & 7;
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (N + 63) / 64;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                   // previous tile fully consumed
+        // ---- stage K (LDS-DMA, swizzled source) ----
+#pragma unroll
+        for (int j = 0; j < KPI; ++j) {
+            const int q = qt * KPI + j;
+            const int row = q * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int key = kt * 64 + row;
+            key = key < N ? key : N - 1;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(base + (size_t)key * QKV_LD + BG_D_MODEL + c * 8),
+                (__attribute__((address_space(3))) void*)(ktile + q * 1024), 16, 0, 0);
+        }
+        // ---- stage V transposed ----
+#pragma unroll
+        for (int j = 0; j < KPI; ++j) {
+            const int idx = (qt * KPI + j) * 64 + lane;
+            const int row = idx >> 3, dc = idx & 7;
+            int key = kt * 64 + row;
+            key = key < N ? key : N - 1;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (size_t)key * QKV_LD + 2 * BG_D_MODEL + dc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vt[(dc * 8 + e) * VS + row] = v[e];
+        }
+        if (tid < 64) {
+            const int key = kt * 64 + tid;
+            const bool dead = key >= N || (key_pad != nullptr && key_pad[(size_t)b * N + key] != 0);
+            mb[tid] = dead ? -INFINITY : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (kt * 64 + sub * 32 >= N) break;            // uniform: sub-tile entirely past the last key
+            // ---- S^T = K Q^T over d = 64 ----
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + k_off[sub] + (((ks * 2 + h) ^ k_sw[sub]) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 mbv = *reinterpret_cast<const float4*>(&mb[sub * 32 + 8 * g4 + 4 * h]);
+                s[4 * g4 + 0] += mbv.x; s[4 * g4 + 1] += mbv.y; s[4 * g4 + 2] += mbv.z; s[4 * g4 + 3] += mbv.w;
+                mloc = fmaxf(mloc, fmaxf(fmaxf(s[4 * g4 + 0], s[4 * g4 + 1]), fmaxf(s[4 * g4 + 2], s[4 * g4 + 3])));
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __expf(m_run - m_use);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __expf(s[r] - m_use);
+                psum += s[r];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            // ---- O^T += V^T P^T : two 16-key slices, two 32-row d tiles ----
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                bf16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = (__bf16)s[8 * sl + e];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const __bf16* vrow = vt + (dt * 32 + (lane & 31)) * VS + sub * 32 + 16 * sl + 4 * h;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
+                    bf16x8 va;
+                    va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                    va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int q = q0 + (lane & 31);
+    if (q < N) {
+        __bf16* op = out + ((size_t)b * N + q) * BG_D_MODEL + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * h;
+                *reinterpret_cast<bf16x4*>(op + d) = to_bf16x4(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv,
+                                                              o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 attention: one wave per (b, head, query).  Scores for keys lane, lane+64, ... in registers/LDS,
+// accurate expf, then lane = d for the P V product.  Parity mode only.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv,
+                                                       const uint8_t* __restrict__ key_pad,
+                                                       float* __restrict__ out, int B, int N) {
+    extern __shared__ float dyn[];                     // 4 waves x N probabilities
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    const int head = blockIdx.y, b = blockIdx.z;
+    float* p = dyn + (size_t)wave * N;
+    if (q >= N) return;                                // no block-level barriers below
+    const float* base = qkv + (size_t)b * N * QKV_LD + head * 64;
+    const float* qp = base + (size_t)q * QKV_LD;
+    float qv[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) qv[d] = qp[d];
+    float mloc = -INFINITY;
+    for (int j = lane; j < N; j += 64) {
+        float sc;
+        if (key_pad != nullptr && key_pad[(size_t)b * N + j] != 0) {
+            sc = -INFINITY;
+        } else {
+            const float* kp = base + (size_t)j * QKV_LD + BG_D_MODEL;
+            sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 64; ++d) sc = fmaf(qv[d], kp[d], sc);
+        }
+        p[j] = sc;
+        mloc = fmaxf(mloc, sc);
+    }
+    const float m = wave_max(mloc);
+    const float m_use = (m == -INFINITY) ? 0.f : m;
+    float lsum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float e = expf(p[j] - m_use);
+        p[j] = e;
+        lsum += e;
+    }
+    const float l = wave_sum(lsum);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float acc = 0.f;                                   // lane = d
+    for (int j = 0; j < N; ++j) acc = fmaf(p[j], base[(size_t)j * QKV_LD + 2 * BG_D_MODEL + lane], acc);
+    out[((size_t)b * N + q) * BG_D_MODEL + head * 64 + lane] = l > 0.f ? acc / l : 0.f;
+}
+
+int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s) {
+    if (B <= 0 || N <= 0) return 0;
+    if (dtype == BG_BF16) {
+        const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
+        __bf16* o = reinterpret_cast<__bf16*>(out);
+        if (N <= 32) {
+            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(1, BG_N_HEAD / 4, B), dim3(256), 0, s, q, key_pad, o, B, N);
+        } else if (N <= 64) {
+            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(1, BG_N_HEAD / 2, B), dim3(256), 0, s, q, key_pad, o, B, N);
+        } else {
+            hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3((N + 127) / 128, BG_N_HEAD, B), dim3(256), 0, s, q, key_pad, o, B, N);
+        }
+        return launch_status("attn_bf16");
+    }
+    if (dtype == BG_F32) {
+        const size_t shm = (size_t)4 * N * sizeof(float);
+        if (shm > 160 * 1024) {
+            set_error("attn_f32: N=%d too long for the parity kernel", N);
+            return BG_E_SHAPE;
+        }
+        if (shm > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((N + 3) / 4, BG_N_HEAD, B), dim3(256), shm, s,
+                           reinterpret_cast<const float*>(qkv), key_pad, reinterpret_cast<float*>(out), B, N);
+        return launch_status("attn_f32");
+    }
+    set_error("attention: unsupported dtype %d", dtype);
+    return BG_E_DTYPE;
+}
+
+}  // namespace bg
+
+extern "C" int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
+                           bg_stream_t stream) {
+    BG_REQUIRE(qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_attn_fwd: null pointer or negative size");
+    BG_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, BG_E_ALIGN, "bg_attn_fwd: 16-byte alignment");
+    return bg::attention(qkv, key_pad, out, B, N, dtype, (hipStream_t)stream);
+}

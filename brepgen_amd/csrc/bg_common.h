@@ -1,0 +1,85 @@
+// Shared device/host helpers for libbrepgen_hip.so (gfx950 only -- wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/brepgen_hip.h"
+
+namespace bg {
+
+// ---- error plumbing (thread-local message behind bg_last_error) ---------------------------------
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipError_t (+message)
+
+#define BG_REQUIRE(cond, code, ...)            \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::bg::set_error(__VA_ARGS__);      \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// ---- vector types -----------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (__bf16)a; r[1] = (__bf16)b; r[2] = (__bf16)c; r[3] = (__bf16)d;   // RNE (v_cvt_pk_bf16_f32)
+    return r;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware bijective remap of a 1-D block id (MI355X: block b runs on XCD b % 8, each XCD has a private
+// 4 MiB L2).  Consecutive *logical* ids land on the same XCD back-to-back, so tiles that share an operand
+// panel hit that XCD's L2 instead of 8 different ones.  Placement is a speed assumption only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// ---- launchers implemented in the kernel files (host side, all asynchronous on `s`) -----------
+struct GemmArgs {
+    const void* a; int lda;
+    const void* w;            // [N_pad, K] row-major
+    const float* bias;        // [N_pad] or null
+    void* out; int ldc;
+    int M, N, N_pad, K;
+    int out_dtype;            // BG_F32 | BG_BF16
+    int act;                  // bg_act
+    const float* add; int ld_add; int add_div;   // optional fp32 addend, row (m / add_div)
+    const float* add2 = nullptr; int ld_add2 = 0; int add2_div = 1;   // optional second addend
+};
+int gemm_f32(const GemmArgs& g, hipStream_t s);
+int gemm_bf16(const GemmArgs& g, hipStream_t s);
+int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s);
+
+int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps,
+                 int silu, hipStream_t s);
+int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s);
+int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
+// c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)
+int cond_vector(const float* temb, int nt, const float* class_embed, const int64_t* label, float* c, int B,
+                hipStream_t s);
+// out = f32 -> bf16 cast (n elements, n % 4 == 0)
+int cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
+
+}  // namespace bg

@@ -1,0 +1,202 @@
+// Whole-net forward of the four BrepGen denoisers (network.py:1107-1126, 1176-1200, 1257-1286, 1357-1393),
+// enqueued on one stream from ONE C-ABI call: batch-first [M = B*N, 768] layout end to end (the reference's
+// seq-first permutes -- 38 % of its CPU time -- do not exist here), fp32 residual stream, activations in the
+// compute dtype, step-invariant conditioning embeds cached across denoising steps.
+#include "bg_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace bg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int launch_status(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+__global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n, int E) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = in[i / E];
+}
+
+static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+    size_t off_x, off_h, off_r, off_small, off_f, off_mask, total;
+    int M, F;
+};
+
+static Workspace plan(int net, int B, int S, int E, int dtype) {
+    Workspace w{};
+    const size_t es = (dtype == BG_F32) ? 4 : 2;
+    w.M = B * S * E;
+    w.F = B * S;
+    size_t o = 0;
+    w.off_x = o; o += align_up((size_t)w.M * 768 * 4);
+    w.off_h = o; o += align_up((size_t)w.M * 768 * es);
+    w.off_r = o; o += align_up((size_t)w.M * 2304 * es);
+    w.off_small = o; o += align_up((size_t)(4 * B + B) * 768 * 4);      // sincos, t0, t1(as fp32 worst case), temb, cvec
+    w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
+    w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
+    w.total = o;
+    return w;
+}
+
+struct Ctx {
+    const bg_denoiser_weights* w;
+    hipStream_t s;
+    int dtype;
+    unsigned char* ws;
+    Workspace p;
+    float* X;
+    void* H;
+    void* R;
+};
+
+// Linear(k,768)+b -> LN -> SiLU -> Linear(768,n)+b (+adds) ; x fp32 rows (lda), or activations in compute dtype for fc_out
+static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, int rows, float* out, int ldc,
+                     const float* add, int ld_add, int add_div, const float* add2, int ld_add2, int add2_div) {
+    float* t0 = reinterpret_cast<float*>(c.R);
+    GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
+    int rc = gemm(g1, m.w0_dtype, c.s);
+    if (rc) return rc;
+    rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s);
+    if (rc) return rc;
+    GemmArgs g2{c.H, 768, m.w3, m.b3, out, ldc, rows, m.n_out, m.n_out_pad, 768, BG_F32, BG_ACT_NONE, add, ld_add,
+                add ? add_div : 1};
+    g2.add2 = add2; g2.ld_add2 = ld_add2; g2.add2_div = add2 ? add2_div : 1;
+    return gemm(g2, c.dtype, c.s);
+}
+
+static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out, void* workspace,
+               size_t ws_bytes, hipStream_t s) {
+    const int net = w->net, B = in->B, S = in->S, E = (net >= BG_EDGEPOS) ? in->E : 1;
+    BG_REQUIRE(net >= BG_SURFPOS && net <= BG_EDGEZ, BG_E_ARG, "bg_denoiser_fwd: bad net id %d", net);
+    BG_REQUIRE(w->dtype == BG_BF16 || w->dtype == BG_F32, BG_E_DTYPE, "bg_denoiser_fwd: compute dtype %d", w->dtype);
+    BG_REQUIRE(B > 0 && S > 0 && E > 0, BG_E_SHAPE, "bg_denoiser_fwd: empty shape B=%d S=%d E=%d", B, S, E);
+    BG_REQUIRE(in->n_timesteps == 1 || in->n_timesteps == B, BG_E_SHAPE, "bg_denoiser_fwd: n_timesteps must be 1 or B");
+    BG_REQUIRE(in->x && in->timesteps && eps_out && workspace, BG_E_ARG, "bg_denoiser_fwd: null pointer");
+    BG_REQUIRE(w->n_layer >= 0 && w->n_layer <= BG_MAX_LAYERS, BG_E_ARG, "bg_denoiser_fwd: n_layer");
+    BG_REQUIRE((w->class_embed == nullptr) || in->class_label, BG_E_ARG, "bg_denoiser_fwd: class_label required (use_cf)");
+    if (net != BG_SURFPOS) BG_REQUIRE(in->surf_pos, BG_E_ARG, "bg_denoiser_fwd: surf_pos missing");
+    if (net >= BG_EDGEPOS) BG_REQUIRE(in->surf_z, BG_E_ARG, "bg_denoiser_fwd: surf_z missing");
+    if (net == BG_EDGEZ) BG_REQUIRE(in->edge_pos, BG_E_ARG, "bg_denoiser_fwd: edge_pos missing");
+    BG_REQUIRE(((uintptr_t)workspace & 255) == 0, BG_E_ALIGN, "bg_denoiser_fwd: workspace must be 256-byte aligned");
+
+    Ctx c;
+    c.w = w; c.s = s; c.dtype = w->dtype;
+    c.p = plan(net, B, S, E, w->dtype);
+    BG_REQUIRE(ws_bytes >= c.p.total, BG_E_WORKSPACE, "bg_denoiser_fwd: workspace %zu < %zu bytes", ws_bytes, c.p.total);
+    c.ws = reinterpret_cast<unsigned char*>(workspace);
+    c.X = reinterpret_cast<float*>(c.ws + c.p.off_x);
+    c.H = c.ws + c.p.off_h;
+    c.R = c.ws + c.p.off_r;
+    const int M = c.p.M, F = c.p.F, N = S * E, nt = in->n_timesteps;
+    float* small = reinterpret_cast<float*>(c.ws + c.p.off_small);
+    float* sc = small;                         // [nt,768] sincos
+    float* temb = small + (size_t)3 * B * 768; // [nt,768]
+    float* cvec = small + (size_t)4 * B * 768; // [B,768] = time (+ class) embedding per sample
+    int rc;
+
+    // ---- time (+class) embedding -> one vector per sample --------------------------------------------------
+    if ((rc = sincos_embed(in->timesteps, nt, sc, s))) return rc;
+    if ((rc = embed_mlp(c, w->time_embed, sc, 768, nt, temb, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
+    if ((rc = cond_vector(temb, nt, w->class_embed, in->class_label, cvec, B, s))) return rc;
+
+    // ---- token embeddings -> X [M,768] fp32 ----------------------------------------------------------------
+    // step-invariant part (per face): SurfZ: p_embed(surfPos); Edge nets: surfp_embed(surfPos)+surfz_embed(surfZ)
+    float* fcond = nullptr;
+    if (net != BG_SURFPOS) {
+        fcond = in->cond_cache ? in->cond_cache : reinterpret_cast<float*>(c.ws + c.p.off_f);
+        if (!(in->cond_cache && in->cond_cache_valid)) {
+            if (net == BG_SURFZ) {
+                if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
+            } else {
+                if ((rc = embed_mlp(c, w->embed[0], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
+                if ((rc = embed_mlp(c, w->embed[1], in->surf_z, 48, F, fcond, 768, fcond, 768, 1, nullptr, 0, 1))) return rc;
+            }
+        }
+    }
+    switch (net) {
+        case BG_SURFPOS:   // tokens = p_embed(x) + c
+            rc = embed_mlp(c, w->embed[0], in->x, 6, M, c.X, 768, cvec, 768, N, nullptr, 0, 1);
+            break;
+        case BG_SURFZ:     // tokens = z_embed(x) + p_embed(surfPos) + c
+            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1);
+            break;
+        case BG_EDGEPOS:   // tokens = edgep_embed(x) + surf[m/E] + c
+            rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E);
+            break;
+        default:           // EdgeZ: edgez_embed(x[:, :12]) + vertp_fc(x[:, 12:]) + edgep_embed(edgePos) + surf[m/E] + c
+            rc = embed_mlp(c, w->embed[3], in->x, 18, M, c.X, 768, cvec, 768, N, fcond, 768, E);
+            if (!rc) rc = embed_mlp(c, w->embed[4], in->x + 12, 18, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1);
+            if (!rc) rc = embed_mlp(c, w->embed[2], in->edge_pos, 6, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1);
+            break;
+    }
+    if (rc) return rc;
+
+    // ---- key-padding mask [B,N] ----------------------------------------------------------------------------
+    const uint8_t* key_pad = in->mask;
+    if (net == BG_EDGEPOS && in->mask) {
+        uint8_t* mexp = c.ws + c.p.off_mask;
+        const size_t n = (size_t)M;
+        const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(expand_mask_kernel, dim3(grid), dim3(256), 0, s, in->mask, mexp, n, E);
+        if ((rc = launch_status("expand_mask"))) return rc;
+        key_pad = mexp;
+    }
+
+    // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
+    for (int li = 0; li < w->n_layer; ++li) {
+        const bg_layer_weights& L = w->layers[li];
+        if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s))) return rc;
+        GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        if ((rc = gemm(qkv, c.dtype, s))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s))) return rc;
+        GemmArgs op{c.H, 768, L.w_o, L.b_o, c.X, 768, M, 768, 768, 768, BG_F32, BG_ACT_NONE, c.X, 768, 1};
+        if ((rc = gemm(op, c.dtype, s))) return rc;
+        if ((rc = layernorm768(c.X, L.ln2_g, L.ln2_b, c.H, c.dtype, M, 1e-5f, 0, s))) return rc;
+        GemmArgs f1{c.H, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
+        if ((rc = gemm(f1, c.dtype, s))) return rc;
+        GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.X, 768, M, 768, 768, 1024, BG_F32, BG_ACT_NONE, c.X, 768, 1};
+        if ((rc = gemm(f2, c.dtype, s))) return rc;
+    }
+
+    // ---- final LayerNorm + fc_out ---------------------------------------------------------------------------
+    // fc_out.0 reads the final-LN output from H and writes its fp32 result to R; the LN+SiLU then overwrites H.
+    {
+        void* hf = c.H;
+        if ((rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s))) return rc;
+        const bg_mlp_weights& m = w->fc_out;
+        rc = embed_mlp(c, m, hf, 768, M, eps_out, m.n_out, nullptr, 0, 1, nullptr, 0, 1);
+    }
+    return rc;
+}
+
+}  // namespace bg
+
+extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
+extern "C" const char* bg_last_error(void) { return bg::g_err; }
+
+extern "C" size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype) {
+    if (B <= 0 || S <= 0) return 0;
+    if (net < BG_EDGEPOS) E = 1;
+    if (E <= 0) return 0;
+    return bg::plan(net, B, S, E, dtype).total;
+}
+
+extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
+                               void* workspace, size_t workspace_bytes, bg_stream_t stream) {
+    BG_REQUIRE(w && in, BG_E_ARG, "bg_denoiser_fwd: null descriptor");
+    return bg::run(w, in, eps_out, workspace, workspace_bytes, (hipStream_t)stream);
+}

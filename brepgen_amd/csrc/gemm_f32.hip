@@ -1,0 +1,100 @@
+// Exact-fp32 GEMM on the f32-input matrix core (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, bitwise the
+// same numerics as a VALU fp32 GEMM, at the 157 TFLOP/s vector rate).  Used for
+//   * every nn.Linear of the fp32 parity mode (BASELINE configs[0], tolerance 1e-5), and
+//   * the tiny-K first Linear of each embed MLP (K = 6 / 12 / 48, network.py:1080-1085) in every mode, so the
+//     raw fp32 inputs (x_t, bboxes, latents) are never rounded to bf16.
+// Any M, N, K; nn.Linear layout w[N,K]; tile 64x64x16, 4 waves (2x2), each wave one 32x32 accumulator.
+#include "bg_common.h"
+
+namespace bg {
+
+constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = F_BK + 1;   // +1 float pad: conflict-free ds_read_b32
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[F_BM * F_LD];
+    __shared__ float Bs[F_BN * F_LD];
+    const float* __restrict__ A = reinterpret_cast<const float*>(g.a);
+    const float* __restrict__ W = reinterpret_cast<const float*>(g.w);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt_n = (g.N + F_BN - 1) / F_BN;
+    const int m0 = (blockIdx.x / nt_n) * F_BM, n0 = (blockIdx.x % nt_n) * F_BN;
+
+    // global -> LDS assignment: thread t loads 4 consecutive k of one row of A and one row of W
+    const int lrow = tid >> 2, lk = (tid & 3) * 4;
+    const int arow = m0 + lrow, wrow = n0 + lrow;
+    const bool a_ok = arow < g.M, w_ok = wrow < g.N_pad;
+    const float* ap = A + (size_t)(a_ok ? arow : 0) * g.lda;
+    const float* wp = W + (size_t)(w_ok ? wrow : 0) * g.K;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += F_BK) {
+        float av[4], wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + lk + j;
+            av[j] = (a_ok && k < g.K) ? ap[k] : 0.f;
+            wv[j] = (w_ok && k < g.K) ? wp[k] : 0.f;
+        }
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[lrow * F_LD + lk + j] = av[j];
+            Bs[lrow * F_LD + lk + j] = wv[j];
+        }
+        __syncthreads();
+        // lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] of each k=2 slice
+        const float* as = &As[(wm * 32 + (lane & 31)) * F_LD + (lane >> 5)];
+        const float* bs = &Bs[(wn * 32 + (lane & 31)) * F_LD + (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < F_BK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[kk * 2], bs[kk * 2], acc, 0, 0, 0);
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= g.N) return;
+    const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = acc[r] + bias;
+        if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+        if (g.add) v += g.add[(size_t)(row / g.add_div) * g.ld_add + col];
+        if (g.add2) v += g.add2[(size_t)(row / g.add2_div) * g.ld_add2 + col];
+        if (g.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(g.out)[(size_t)row * g.ldc + col] = (__bf16)v;
+        else reinterpret_cast<float*>(g.out)[(size_t)row * g.ldc + col] = v;
+    }
+}
+
+int gemm_f32(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return 0;
+    const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(nblk), dim3(256), 0, s, g);
+    return launch_status("gemm_f32");
+}
+
+int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s) {
+    if (ab_dtype == BG_F32) return gemm_f32(g, s);
+    if (ab_dtype == BG_BF16) return gemm_bf16(g, s);
+    set_error("gemm: unsupported operand dtype %d", ab_dtype);
+    return BG_E_DTYPE;
+}
+
+}  // namespace bg
+
+extern "C" int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const float* bias, void* out, int ldc,
+                                    int M, int N, int N_pad, int K, int ab_dtype, int out_dtype, int act,
+                                    const float* add, int ld_add, int add_div, bg_stream_t stream) {
+    BG_REQUIRE(a && w && out, BG_E_ARG, "bg_gemm_bias_act_fwd: null pointer");
+    BG_REQUIRE(M >= 0 && N > 0 && K > 0 && N_pad >= N && lda >= K && ldc >= N, BG_E_SHAPE,
+               "bg_gemm_bias_act_fwd: bad shape M=%d N=%d N_pad=%d K=%d lda=%d ldc=%d", M, N, N_pad, K, lda, ldc);
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_gemm_bias_act_fwd: out dtype %d", out_dtype);
+    BG_REQUIRE(add == nullptr || add_div >= 1, BG_E_ARG, "bg_gemm_bias_act_fwd: add_div must be >= 1");
+    bg::GemmArgs g{a, lda, w, bias, out, ldc, M, N, N_pad, K, out_dtype, act, add, ld_add, add ? add_div : 1};
+    return bg::gemm(g, ab_dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,310 @@
+"""Drop-in mirrors of BrepGen's four transformer denoisers, running on hand-written gfx950 kernels.
+
+Same constructor / ``forward`` signatures and the same checkpoint key layout as the reference classes
+(/root/reference/network.py:1066-1393; key layout SURVEY.md App. A.3), so ``load_state_dict`` of a published
+``*_ldm_*.pt`` works unchanged -- but ``forward`` is ONE call into libbrepgen_hip.so (``bg_denoiser_fwd``): the
+``nn.Module`` tree below only *holds* the fp32 parameters.
+
+Precision: like the reference, the module follows autocast -- inside ``torch.autocast('cuda')`` (as sample.py:121
+runs it) GEMM/attention operands are bf16 with fp32 accumulation, an fp32 residual stream and fp32 LayerNorm /
+softmax statistics; outside autocast everything is exact fp32 (f32-input MFMA).  ``compute_dtype`` overrides.
+The returned eps is always fp32.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import (BG_BF16, BG_EDGEPOS, BG_EDGEZ, BG_F32, BG_SURFPOS, BG_SURFZ, DenoiserInputs, DenoiserWeights,
+                   check, ptr, stream)
+
+D, H, DFF, NLAYER = 768, 12, 1024, 12
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (names chosen to reproduce the reference's state-dict keys exactly)
+# --------------------------------------------------------------------------------------------------
+class _Embedder(nn.Module):                      # network.py:17-27  -> key "class_embed.embed.weight"
+    def __init__(self, vocab, dim):
+        super().__init__()
+        self.embed = nn.Embedding(vocab, dim)
+        nn.init.kaiming_normal_(self.embed.weight, mode="fan_in")
+
+
+class _AttnParams(nn.Module):                    # keys self_attn.{in_proj_weight,in_proj_bias,out_proj.*}
+    def __init__(self):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * D, D))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * D))
+        self.out_proj = nn.Linear(D, D)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _LayerParams(nn.Module):                   # keys net.layers.i.{self_attn,linear1,linear2,norm1,norm2}
+    def __init__(self):
+        super().__init__()
+        self.self_attn = _AttnParams()
+        self.linear1 = nn.Linear(D, DFF)
+        self.linear2 = nn.Linear(DFF, D)
+        self.norm1 = nn.LayerNorm(D)
+        self.norm2 = nn.LayerNorm(D)
+
+
+class _EncoderParams(nn.Module):                 # keys net.layers.*, net.norm.*
+    def __init__(self, n_layer=NLAYER):
+        super().__init__()
+        self.layers = nn.ModuleList([_LayerParams() for _ in range(n_layer)])
+        self.norm = nn.LayerNorm(D)
+
+
+def _mlp(k_in, k_out):                           # keys <name>.{0,1,3}.{weight,bias}
+    return nn.Sequential(nn.Linear(k_in, D), nn.LayerNorm(D), nn.SiLU(), nn.Linear(D, k_out))
+
+
+# --------------------------------------------------------------------------------------------------
+class _HipDenoiser(nn.Module):
+    NET = None            # bg_net id
+    EMBEDS = ()           # embed-MLP attribute names in the order of bg_denoiser_weights.embed[]
+    OUT = 0               # eps channels
+
+    def __init__(self, use_cf):
+        super().__init__()
+        self.embed_dim = D
+        self.use_cf = use_cf
+        self.net = _EncoderParams()
+        self.compute_dtype = None        # None: follow autocast (bf16 inside, fp32 outside)
+        self.cache_conditioning = True   # reuse step-invariant conditioning embeds while the inputs are unchanged
+        self._packs = {}
+        self._workspace = None
+        self._cond = None                # conditioning-embed cache entry
+
+    # ---- weight packing -------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packs, self._cond = {}, None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packs, self._cond = {}, None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate(self):
+        """Call after mutating parameters in place (e.g. an optimizer step)."""
+        self._packs, self._cond = {}, None
+
+    def _pack(self, dt):
+        if dt in self._packs:
+            return self._packs[dt]
+        keep = []                                        # owns every packed tensor the descriptor points to
+        code = BG_BF16 if dt == torch.bfloat16 else BG_F32
+
+        def f32(p):
+            t = p.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def mat(p, scale_rows=0, pad_to=1):
+            t = p.detach().to(torch.float32)
+            if scale_rows:                               # fold the 1/sqrt(64) softmax scale into the q rows (exact)
+                t = t.clone()
+                t[:scale_rows] *= 0.125
+            if t.shape[0] % pad_to:
+                t = torch.cat([t, t.new_zeros((-t.shape[0]) % pad_to, *t.shape[1:])])
+            t = t.to(dt).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        pad = 64 if dt == torch.bfloat16 else 1
+
+        def mlp(seq, w0_compute=False):
+            m = _lib.MlpWeights()
+            k_in, n_out = seq[0].in_features, seq[3].out_features
+            m.w0 = mat(seq[0].weight) if w0_compute else f32(seq[0].weight)
+            m.w0_dtype = code if w0_compute else BG_F32
+            m.b0, m.ln_g, m.ln_b = f32(seq[0].bias), f32(seq[1].weight), f32(seq[1].bias)
+            m.w3 = mat(seq[3].weight, pad_to=pad)
+            b3 = seq[3].bias.detach().to(torch.float32)
+            if b3.numel() % pad:
+                b3 = torch.cat([b3, b3.new_zeros((-b3.numel()) % pad)])
+            m.b3 = f32(b3)
+            m.k_in, m.n_out = k_in, n_out
+            m.n_out_pad = n_out + ((-n_out) % pad)
+            return m
+
+        w = DenoiserWeights()
+        w.net, w.dtype, w.n_layer = self.NET, code, len(self.net.layers)
+        for i, layer in enumerate(self.net.layers):
+            L = w.layers[i]
+            L.ln1_g, L.ln1_b = f32(layer.norm1.weight), f32(layer.norm1.bias)
+            L.ln2_g, L.ln2_b = f32(layer.norm2.weight), f32(layer.norm2.bias)
+            L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D)
+            bq = layer.self_attn.in_proj_bias.detach().to(torch.float32).clone()
+            bq[:D] *= 0.125
+            L.b_qkv = f32(bq)
+            L.w_o, L.b_o = mat(layer.self_attn.out_proj.weight), f32(layer.self_attn.out_proj.bias)
+            L.w_1, L.b_1 = mat(layer.linear1.weight), f32(layer.linear1.bias)
+            L.w_2, L.b_2 = mat(layer.linear2.weight), f32(layer.linear2.bias)
+        w.lnf_g, w.lnf_b = f32(self.net.norm.weight), f32(self.net.norm.bias)
+        w.time_embed = mlp(self.time_embed)
+        w.fc_out = mlp(self.fc_out, w0_compute=True)
+        for i, name in enumerate(self.EMBEDS):
+            w.embed[i] = mlp(getattr(self, name))
+        w.class_embed = f32(self.class_embed.embed.weight) if self.use_cf else None
+        self._packs[dt] = (w, keep)
+        return self._packs[dt]
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    def _ws(self, nbytes, device):
+        if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._workspace
+
+    @staticmethod
+    def _f32(t):
+        return t.detach().to(torch.float32).contiguous()
+
+    def _labels(self, class_label, bsz, is_train, device):
+        if not self.use_cf:
+            return None
+        if class_label is None:
+            raise ValueError("use_cf=True needs class_label")
+        if is_train:                                   # network.py:1114-1118: drop 10 % of the labels to 'uncond'
+            uncond = torch.rand(bsz, 1) <= 0.1
+            class_label[uncond.to(class_label.device)] = 0
+        return class_label.reshape(-1).to(device=device, dtype=torch.int64).contiguous()
+
+    def _run(self, x, timesteps, surf_pos, surf_z, edge_pos, mask, class_label, B, S, E, out_shape):
+        if not x.is_cuda:
+            raise _lib.BrepgenHipError("brepgen_amd denoisers run on the MI355X only (tensor on "
+                                       f"{x.device}); there is no CPU fallback")
+        dt = self._dtype()
+        w, _keep = self._pack(dt)
+        dev = x.device
+        t = timesteps.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        if t.numel() not in (1, B):
+            raise ValueError("timesteps must hold 1 or batch-size entries")
+        mk = None
+        if mask is not None:
+            mk = mask.contiguous()
+            mk = mk.view(torch.uint8) if mk.dtype == torch.bool else mk.to(torch.uint8)
+        inp = DenoiserInputs()
+        inp.B, inp.S, inp.E, inp.n_timesteps = B, S, E, t.numel()
+        inp.x, inp.surf_pos, inp.surf_z, inp.edge_pos = ptr(x), ptr(surf_pos), ptr(surf_z), ptr(edge_pos)
+        inp.mask, inp.timesteps, inp.class_label = ptr(mk), ptr(t), ptr(class_label)
+        # step-invariant conditioning cache, keyed on the identity + version of the conditioning tensors
+        inp.cond_cache, inp.cond_cache_valid = None, 0
+        if self.cache_conditioning and surf_pos is not None and not self.training:
+            # The cache entry holds references to the tensors it was computed from: their storage cannot be
+            # recycled for other data while cached, so object identity + in-place version is a sound key.
+            conds = [c for c in (surf_pos, surf_z) if c is not None]
+            vers = [c._version for c in conds]
+            hit = (self._cond is not None and self._cond["meta"] == (dt, B, S) and
+                   len(self._cond["src"]) == len(conds) and
+                   all(a is b for a, b in zip(self._cond["src"], conds)) and self._cond["ver"] == vers)
+            if not hit:
+                self._cond = {"meta": (dt, B, S), "src": conds, "ver": vers, "valid": False,
+                              "buf": torch.empty(B * S, D, device=dev, dtype=torch.float32)}
+            inp.cond_cache = ptr(self._cond["buf"])
+            inp.cond_cache_valid = int(self._cond["valid"])
+            self._cond["valid"] = True
+        out = torch.empty(out_shape, device=dev, dtype=torch.float32)
+        lib = _lib.load()
+        nbytes = lib.bg_workspace_bytes(self.NET, B, S, E, w.dtype)
+        ws = self._ws(nbytes, dev)
+        check(lib.bg_denoiser_fwd(C.byref(w), C.byref(inp), ptr(out), ptr(ws), ws.numel(), stream()),
+              f"bg_denoiser_fwd[{type(self).__name__}]")
+        return out
+
+
+class SurfPosNet(_HipDenoiser):
+    """Face-bbox denoiser; signature of network.py:1071,1107."""
+    NET, EMBEDS, OUT = BG_SURFPOS, ("p_embed",), 6
+
+    def __init__(self, use_cf):
+        super().__init__(use_cf)
+        self.p_embed = _mlp(6, D)
+        self.time_embed = _mlp(D, D)
+        self.fc_out = _mlp(D, 6)
+        if use_cf:
+            self.class_embed = _Embedder(11, D)
+
+    def forward(self, surfPos, timesteps, class_label, is_train=False):
+        B, S = surfPos.shape[:2]
+        cl = self._labels(class_label, B, is_train, surfPos.device)
+        return self._run(self._f32(surfPos), timesteps, None, None, None, None, cl, B, S, 1, (B, S, 6))
+
+
+class SurfZNet(_HipDenoiser):
+    """Face-latent denoiser; signature of network.py:1133,1176."""
+    NET, EMBEDS, OUT = BG_SURFZ, ("z_embed", "p_embed"), 48
+
+    def __init__(self, use_cf):
+        super().__init__(use_cf)
+        self.z_embed = _mlp(48, D)
+        self.p_embed = _mlp(6, D)
+        self.time_embed = _mlp(D, D)
+        self.fc_out = _mlp(D, 48)
+        if use_cf:
+            self.class_embed = _Embedder(11, D)
+
+    def forward(self, surfZ, timesteps, surfPos, surf_mask, class_label, is_train=False):
+        B, S = surfZ.shape[:2]
+        cl = self._labels(class_label, B, is_train, surfZ.device)
+        return self._run(self._f32(surfZ), timesteps, self._keep(surfPos), None, None, surf_mask, cl, B, S, 1,
+                         (B, S, 48))
+
+    @staticmethod
+    def _keep(t):
+        # keep the caller's tensor object when it is already dense fp32 so the conditioning cache can key on it
+        return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().to(torch.float32).contiguous()
+
+
+class EdgePosNet(_HipDenoiser):
+    """Edge-bbox denoiser; signature of network.py:1207,1257."""
+    NET, EMBEDS, OUT = BG_EDGEPOS, ("surfp_embed", "surfz_embed", "edgep_embed"), 6
+
+    def __init__(self, use_cf):
+        super().__init__(use_cf)
+        self.surfz_embed = _mlp(48, D)
+        self.surfp_embed = _mlp(6, D)
+        self.edgep_embed = _mlp(6, D)
+        self.time_embed = _mlp(D, D)
+        self.fc_out = _mlp(D, 6)
+        if use_cf:
+            self.class_embed = _Embedder(11, D)
+
+    def forward(self, edgePos, timesteps, surfPos, surfZ, mask, class_label, is_train=False):
+        B, S, E = edgePos.shape[:3]
+        cl = self._labels(class_label, B, is_train, edgePos.device)
+        k = SurfZNet._keep
+        return self._run(self._f32(edgePos), timesteps, k(surfPos), k(surfZ), None, mask, cl, B, S, E, (B, S, E, 6))
+
+
+class EdgeZNet(_HipDenoiser):
+    """Edge-latent + vertex denoiser; signature of network.py:1293,1357."""
+    NET, EMBEDS, OUT = BG_EDGEZ, ("surfp_embed", "surfz_embed", "edgep_embed", "edgez_embed", "vertp_fc"), 18
+
+    def __init__(self, use_cf):
+        super().__init__(use_cf)
+        self.surfz_embed = _mlp(48, D)
+        self.edgez_embed = _mlp(12, D)
+        self.surfp_embed = _mlp(6, D)
+        self.edgep_embed = _mlp(6, D)
+        self.vertp_fc = _mlp(6, D)
+        self.time_embed = _mlp(D, D)
+        self.fc_out = _mlp(D, 18)
+        if use_cf:
+            self.class_embed = _Embedder(11, D)
+
+    def forward(self, edge, timesteps, edgePos, surfPos, surfZ, mask, class_label, is_train=False):
+        B, S, E = edgePos.shape[:3]
+        cl = self._labels(class_label, B, is_train, edge.device)
+        k = SurfZNet._keep
+        return self._run(self._f32(edge), timesteps, k(surfPos), k(surfZ), self._f32(edgePos), mask, cl, B, S, E,
+                         (B, S, E, 18))

@@ -1,0 +1,75 @@
+"""Thin tensor-level wrappers over the C ABI (one function per exported kernel entry point).
+
+Used by the drop-in modules and by the parity tests; every function enqueues on the current torch HIP stream
+and returns torch tensors that own the output memory.  No torch math here -- only allocation and pointers.
+"""
+import torch
+
+from . import _lib
+from ._lib import BG_ACT_NONE, BG_ACT_RELU, BG_BF16, BG_F32, check, ptr, stream  # noqa: F401
+
+_DT = {torch.float32: BG_F32, torch.bfloat16: BG_BF16}
+
+
+def bg_dtype(dt):
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"brepgen_amd supports float32 and bfloat16 compute, not {dt}") from None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.BrepgenHipError("brepgen_amd kernels run on the MI355X only: tensor is on "
+                                       f"{t.device}; there is no CPU fallback")
+
+
+def sincos_embed(timesteps):
+    _need_cuda(timesteps)
+    t = timesteps.reshape(-1).to(torch.int64).contiguous()
+    out = torch.empty(t.numel(), 768, device=t.device, dtype=torch.float32)
+    check(_lib.load().bg_sincos_embed(ptr(t), t.numel(), ptr(out), stream()), "bg_sincos_embed")
+    return out
+
+
+def layernorm(x, gamma, beta, out_dtype=torch.float32, eps=1e-5, silu=False):
+    _need_cuda(x, gamma, beta)
+    assert x.dtype == torch.float32 and x.shape[-1] == 768
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    M = x.numel() // 768
+    check(_lib.load().bg_layernorm_fwd(ptr(x), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(y),
+                                       bg_dtype(out_dtype), M, eps, int(silu), stream()), "bg_layernorm_fwd")
+    return y
+
+
+def linear(a, w, bias=None, out_dtype=torch.float32, act=BG_ACT_NONE, add=None, add_div=1, n_valid=None, out=None):
+    """out = act(a @ w.T + bias) + add[m // add_div]; a [M,K], w [N_pad,K] (same dtype), n_valid <= N_pad."""
+    _need_cuda(a, w, bias, add)
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1]
+    a, w = a.contiguous(), w.contiguous()
+    M, K = a.shape
+    n_pad = w.shape[0]
+    N = n_pad if n_valid is None else n_valid
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype)
+    ld_add = add.shape[-1] if add is not None else 0
+    check(_lib.load().bg_gemm_bias_act_fwd(ptr(a), K, ptr(w), ptr(bias), ptr(out), out.shape[1], M, N, n_pad, K,
+                                           bg_dtype(a.dtype), bg_dtype(out.dtype), act, ptr(add), ld_add, add_div,
+                                           stream()), "bg_gemm_bias_act_fwd")
+    return out
+
+
+def attention(qkv, key_pad, B, N):
+    """qkv [B*N, 2304] (q pre-scaled by 1/8), key_pad bool/uint8 [B,N] or None -> [B*N, 768]."""
+    _need_cuda(qkv, key_pad)
+    qkv = qkv.contiguous()
+    assert qkv.shape == (B * N, 2304)
+    kp = None
+    if key_pad is not None:
+        kp = key_pad.contiguous()
+        kp = kp.view(torch.uint8) if kp.dtype == torch.bool else kp.to(torch.uint8)
+    out = torch.empty(B * N, 768, device=qkv.device, dtype=qkv.dtype)
+    check(_lib.load().bg_attn_fwd(ptr(qkv), ptr(kp), ptr(out), B, N, bg_dtype(qkv.dtype), stream()), "bg_attn_fwd")
+    return out

@@ -1,0 +1,174 @@
+/*
+ * brepgen_hip.h -- C ABI of libbrepgen_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (samxuxiang/BrepGen) has no FFI / plugin layer: its hot path is
+ * Python calling torch ops.  This ABI is therefore the boundary a maintainer
+ * would bind *under* the reference's Python call surface; every entry point
+ * names the reference code it replaces (file:line in /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. the PyTorch
+ *     caching allocator), including the workspace; the library never allocates,
+ *     never synchronises, keeps no global state; everything is enqueued on the
+ *     `stream` argument (pass torch.cuda.current_stream().cuda_stream);
+ *   - tensors are dense row-major, batch-first: tokens [B, N, C] == rows [M=B*N, C];
+ *   - return 0 on success, a positive hipError_t from the launch, or a negative
+ *     BG_E_* argument error; bg_last_error() gives the thread-local message;
+ *   - nothing throws across the boundary.
+ */
+#ifndef BREPGEN_HIP_H
+#define BREPGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_ABI_VERSION 1
+
+typedef void* bg_stream_t;              /* hipStream_t */
+
+enum bg_dtype { BG_F32 = 0, BG_F16 = 1, BG_BF16 = 2 };
+enum bg_act { BG_ACT_NONE = 0, BG_ACT_RELU = 1 };
+enum bg_net { BG_SURFPOS = 0, BG_SURFZ = 1, BG_EDGEPOS = 2, BG_EDGEZ = 3 };
+enum bg_err { BG_E_ARG = -1, BG_E_SHAPE = -2, BG_E_WORKSPACE = -3, BG_E_DTYPE = -4, BG_E_ALIGN = -5 };
+
+#define BG_D_MODEL 768
+#define BG_N_HEAD 12
+#define BG_D_HEAD 64
+#define BG_D_FF 1024
+#define BG_MAX_LAYERS 12
+#define BG_MAX_EMBEDS 5
+
+int bg_abi_version(void);
+const char* bg_last_error(void);
+
+/* ---- elementwise / normalisation ------------------------------------------------------ */
+
+/* network.py:1043-1063 sincos_embedding: out[i, 0:384]=cos(t_i*f), out[i,384:768]=sin(t_i*f). */
+int bg_sincos_embed(const int64_t* timesteps, int n, float* out /*[n,768]*/, bg_stream_t stream);
+
+/* torch.nn.LayerNorm(768, eps) as used at network.py:1076-1099 (optionally followed by SiLU, the
+ * `LayerNorm -> SiLU` pair inside every embed MLP).  x fp32 [M,768]; y fp32 or bf16 [M,768]. */
+int bg_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                     int M, float eps, int fuse_silu, bg_stream_t stream);
+
+/* nn.Linear (+ReLU) (+residual / broadcast add) -- every addmm of network.py:1076-1099.
+ *   out[m,n] = act(sum_k a[m,k]*w[n,k] + bias[n]) + (add ? add[(m/add_div)*ld_add + n] : 0)
+ * a: [M,K] dtype ab_dtype (BG_F32 or BG_BF16), row stride lda; w: [N_pad,K] same dtype (nn.Linear
+ * layout, row stride K); out: fp32 or bf16, row stride ldc, only columns < N are written.
+ * BG_BF16: K % 64 == 0, N_pad % 64 == 0 (weights zero-padded by the packer).  BG_F32: any shape.
+ * `add` may alias `out` (in-place residual, add_div = 1). */
+int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const float* bias, void* out, int ldc,
+                         int M, int N, int N_pad, int K, int ab_dtype, int out_dtype, int act,
+                         const float* add, int ld_add, int add_div, bg_stream_t stream);
+
+/* F.scaled_dot_product_attention inside nn.MultiheadAttention (network.py:1076-1078 via
+ * torch/nn/modules/transformer.py slow path): qkv packed [B*N, 2304] (q|k|v, head h at columns
+ * 64h..64h+63 of each third; q already multiplied by 1/8), key_pad uint8 [B,N] (1 = padded key, -inf)
+ * or NULL; out [B*N,768].  dtype BG_BF16 or BG_F32.  A sample whose keys are all padded yields 0
+ * (the reference yields NaN there; the pipeline never produces such a sample, sample.py:163,261). */
+int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
+                bg_stream_t stream);
+
+/* ---- whole denoiser -------------------------------------------------------------------- */
+
+typedef struct {            /* Linear(k_in,768) -> LayerNorm -> SiLU -> Linear(768,n_out)   (sub-keys .0 .1 .3) */
+    const void* w0;         /* [768,k_in]; fp32 for the input/time embeds (tiny K or M: exact fp32 MFMA),
+                               compute dtype for fc_out (K = 768, M = all tokens) */
+    const float* b0;
+    const float* ln_g;
+    const float* ln_b;
+    const void* w3;         /* compute dtype [n_out_pad,768] */
+    const float* b3;        /* fp32 [n_out_pad] */
+    int k_in, n_out, n_out_pad, w0_dtype;
+} bg_mlp_weights;
+
+typedef struct {            /* one nn.TransformerEncoderLayer (norm_first) */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const void* w_qkv;      /* [2304,768], q rows pre-scaled by 1/8 */
+    const float* b_qkv;     /* q part pre-scaled */
+    const void* w_o;        /* [768,768]  */
+    const float* b_o;
+    const void* w_1;        /* [1024,768] */
+    const float* b_1;
+    const void* w_2;        /* [768,1024] */
+    const float* b_2;
+} bg_layer_weights;
+
+typedef struct {
+    int net;                /* enum bg_net */
+    int dtype;              /* GEMM/attention operand dtype: BG_BF16 or BG_F32 */
+    int n_layer;            /* 12 */
+    int _pad;
+    bg_layer_weights layers[BG_MAX_LAYERS];
+    const float *lnf_g, *lnf_b;            /* net.norm */
+    bg_mlp_weights time_embed;
+    bg_mlp_weights fc_out;
+    /* SurfPos: {p_embed}; SurfZ: {z_embed,p_embed}; EdgePos: {surfp,surfz,edgep};
+     * EdgeZ: {surfp,surfz,edgep,edgez,vertp} */
+    bg_mlp_weights embed[BG_MAX_EMBEDS];
+    const float* class_embed;              /* fp32 [11,768] or NULL (use_cf=False) */
+} bg_denoiser_weights;
+
+typedef struct {
+    int B, S, E;            /* E = 1 for the surface nets; tokens per sample N = S*E */
+    int n_timesteps;        /* 1 (sampling) or B (training-style per-sample t) */
+    const float* x;         /* noisy input: SurfPos [B,S,6] | SurfZ [B,S,48] | EdgePos [B,S,E,6] | EdgeZ [B,S,E,18] */
+    const float* surf_pos;  /* [B,S,6]   (SurfZ, EdgePos, EdgeZ) */
+    const float* surf_z;    /* [B,S,48]  (EdgePos, EdgeZ) */
+    const float* edge_pos;  /* [B,S,E,6] (EdgeZ) */
+    const uint8_t* mask;    /* 1 = padded. SurfZ/EdgePos: [B,S]; EdgeZ: [B,S,E]; SurfPos: NULL */
+    const int64_t* timesteps;
+    const int64_t* class_label;  /* [B] or NULL */
+    float* cond_cache;      /* optional [B*S,768] fp32: step-invariant conditioning embeds */
+    int cond_cache_valid;   /* 1: reuse cond_cache, 0: (re)compute and store if cond_cache != NULL */
+    int _pad;
+} bg_denoiser_inputs;
+
+/* bytes of scratch bg_denoiser_fwd needs for these shapes */
+size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype);
+
+/* {SurfPosNet,SurfZNet,EdgePosNet,EdgeZNet}.forward -- network.py:1107-1126,1176-1200,1257-1286,
+ * 1357-1393.  eps_out fp32, shaped like in->x. */
+int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
+                    void* workspace, size_t workspace_bytes, bg_stream_t stream);
+
+/* ---- scheduler steps (diffusers==0.27 arithmetic, called at sample.py:137,153,202,222,236,282) */
+
+/* DDPMScheduler.step fused with the classifier-free-guidance combine (sample.py:132-134):
+ *   eps = eps_c*(1+w) - eps_u*w   (eps_u NULL -> eps = eps_c)
+ *   x0  = clamp((x - sqrt_beta_prod*eps) / sqrt_alpha_prod, +-clip)   (clip <= 0: no clamp)
+ *   out = x0_coeff*x0 + xt_coeff*x + sigma*noise                      (noise NULL or sigma==0: skipped)
+ * scalars are computed on the host in fp32 (brepgen_amd.schedulers).  n = element count. */
+int bg_cfg_ddpm_step(const float* eps_c, const float* eps_u, float guidance_w, const float* x,
+                     const float* noise, float* out, size_t n, float sqrt_alpha_prod,
+                     float sqrt_beta_prod, float x0_coeff, float xt_coeff, float sigma, float clip,
+                     bg_stream_t stream);
+
+/* PNDMScheduler.step (PRK + PLMS) as one fused pass.
+ *   e      = eps_c*(1+w) - eps_u*w
+ *   if store_e:  e_store = e                       (PRK phase 0 / every PLMS step: the `ets` history)
+ *   comb   = c_e*e + c_acc*acc + sum_i c_hist[i]*hist[i]
+ *   if acc_mode==1: acc_out = acc_scale_old*acc + acc_scale_e*e    (PRK running cur_model_output)
+ *   out    = sample_coeff*x - eps_coeff*comb
+ */
+int bg_pndm_step(const float* eps_c, const float* eps_u, float guidance_w, const float* x,
+                 float* e_store, const float* acc, float* acc_out, float acc_scale_old,
+                 float acc_scale_e, float c_e, float c_acc, const float* hist0, const float* hist1,
+                 const float* hist2, float c_h0, float c_h1, float c_h2, float sample_coeff,
+                 float eps_coeff, float* out, size_t n, bg_stream_t stream);
+
+/* DDPMScheduler.add_noise (training-time forward diffusion, trainer.py:348,399,515,...):
+ *   out[b,:] = sqrt_alpha_prod[b] * x0[b,:] + sqrt_one_minus_alpha_prod[b] * noise[b,:]
+ * the two per-sample scalar vectors are device fp32 [B] (gathered from alphas_cumprod by the host shim). */
+int bg_add_noise(const float* x0, const float* noise, const float* sqrt_alpha_prod,
+                 const float* sqrt_one_minus_alpha_prod, float* out, int B, size_t per_sample,
+                 bg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
