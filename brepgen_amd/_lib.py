@@ -44,6 +44,11 @@ class DenoiserInputs(C.Structure):
                 ("cond_cache_valid", C.c_int), ("_pad", C.c_int)]
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("launches", C.c_int), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 _SIGNATURES = {
     "bg_abi_version": (C.c_int, []),
     "bg_last_error": (C.c_char_p, []),
@@ -58,6 +63,8 @@ _SIGNATURES = {
     "bg_pndm_step": (C.c_int, [fp, fp, C.c_float, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp,
                                C.c_size_t, vp]),
+    "bg_profile_begin": (C.c_int, [C.c_int]),
+    "bg_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int]),
     "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
@@ -104,3 +111,23 @@ def ptr(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+class profile:
+    """Context manager around bg_profile_begin/end: `with profile() as p: ...; p.rows` -> list of dicts."""
+
+    def __init__(self, max_launches=20000):
+        self.max_launches, self.rows = max_launches, []
+
+    def __enter__(self):
+        check(load().bg_profile_begin(self.max_launches), "bg_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        buf = (ProfileRow * 16)()
+        n = load().bg_profile_end(buf, 16)
+        if n < 0:
+            check(n, "bg_profile_end")
+        self.rows = [{"kernel": buf[i].kernel.decode(), "launches": buf[i].launches, "total_ms": buf[i].total_ms,
+                      "flops": buf[i].flops, "bytes": buf[i].bytes} for i in range(n)]
+        return False

@@ -225,6 +225,10 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s) {
     if (B <= 0 || N <= 0) return 0;
+    const double es = dtype == BG_BF16 ? 2.0 : 4.0;
+    // algorithmic: QK^T + PV over all heads, no mask discount; bytes: qkv read once, out written once
+    ProfScope prof(dtype == BG_BF16 ? PK_ATTN_BF16 : PK_ATTN_F32, 4.0 * B * BG_N_HEAD * (double)N * N * BG_D_HEAD,
+                   es * B * (double)N * (QKV_LD + BG_D_MODEL), s);
     if (dtype == BG_BF16) {
         const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
         __bf16* o = reinterpret_cast<__bf16*>(out);

@@ -19,6 +19,20 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
         }                                      \
     } while (0)
 
+// ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
+enum ProfKernel { PK_GEMM_BF16_128 = 0, PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_COUNT };
+extern bool g_prof_on;
+void prof_pre(hipStream_t s);
+void prof_post(int kernel, double flops, double bytes, hipStream_t s);
+struct ProfScope {      // records a hipEvent pair around one launch when profiling is enabled
+    int k; double f, b; hipStream_t s;
+    ProfScope(int kernel, double flops, double bytes, hipStream_t st) : k(kernel), f(flops), b(bytes), s(st) {
+        if (g_prof_on) prof_pre(s);
+    }
+    ~ProfScope() { if (g_prof_on) prof_post(k, f, b, s); }
+};
+
 // ---- vector types -----------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

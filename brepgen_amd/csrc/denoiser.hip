@@ -24,6 +24,32 @@ int launch_status(const char* what) {
     return (int)e;
 }
 
+// ---- per-kernel event timing ------------------------------------------------------------------------------
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t e0, e1; int kernel; double flops, bytes; };
+ProfRec* g_recs = nullptr;
+int g_cap = 0, g_n = 0;
+bool g_open = false;
+const char* const kProfNames[PK_COUNT] = {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_f32", "attn_bf16", "attn_f32",
+                                          "layernorm768", "cfg_ddpm_step", "pndm_step", "misc"};
+}  // namespace
+
+void prof_pre(hipStream_t s) {
+    g_open = false;
+    if (g_n >= g_cap) return;
+    if (hipEventRecord(g_recs[g_n].e0, s) == hipSuccess) g_open = true;
+}
+
+void prof_post(int kernel, double flops, double bytes, hipStream_t s) {
+    if (!g_open) return;
+    g_open = false;
+    ProfRec& r = g_recs[g_n];
+    if (hipEventRecord(r.e1, s) != hipSuccess) return;
+    r.kernel = kernel; r.flops = flops; r.bytes = bytes;
+    ++g_n;
+}
+
 __global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n, int E) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = in[i / E];
@@ -184,6 +210,43 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
 }
 
 }  // namespace bg
+
+extern "C" int bg_profile_begin(int max_launches) {
+    using namespace bg;
+    BG_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), BG_E_ARG, "bg_profile_begin: bad max_launches");
+    BG_REQUIRE(g_recs == nullptr, BG_E_ARG, "bg_profile_begin: already profiling");
+    g_recs = new ProfRec[max_launches];
+    for (int i = 0; i < max_launches; ++i) {
+        if (hipEventCreate(&g_recs[i].e0) != hipSuccess || hipEventCreate(&g_recs[i].e1) != hipSuccess) {
+            set_error("bg_profile_begin: hipEventCreate failed");
+            return BG_E_ARG;
+        }
+    }
+    g_cap = max_launches; g_n = 0; g_prof_on = true;
+    return 0;
+}
+
+extern "C" int bg_profile_end(bg_profile_row* rows, int max_rows) {
+    using namespace bg;
+    BG_REQUIRE(g_recs != nullptr, BG_E_ARG, "bg_profile_end: not profiling");
+    g_prof_on = false;
+    (void)hipDeviceSynchronize();            // measurement aid only -- never on the product path
+    bg_profile_row agg[PK_COUNT];
+    for (int k = 0; k < PK_COUNT; ++k) agg[k] = bg_profile_row{kProfNames[k], 0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < g_n; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_recs[i].e0, g_recs[i].e1) != hipSuccess) continue;
+        bg_profile_row& a = agg[g_recs[i].kernel];
+        a.launches += 1; a.total_ms += ms; a.flops += g_recs[i].flops; a.bytes += g_recs[i].bytes;
+    }
+    for (int i = 0; i < g_cap; ++i) { (void)hipEventDestroy(g_recs[i].e0); (void)hipEventDestroy(g_recs[i].e1); }
+    delete[] g_recs;
+    g_recs = nullptr; g_cap = 0; g_n = 0;
+    int n = 0;
+    for (int k = 0; k < PK_COUNT && n < max_rows; ++k)
+        if (agg[k].launches > 0 && rows) rows[n++] = agg[k];
+    return n;
+}
 
 extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
 extern "C" const char* bg_last_error(void) { return bg::g_err; }

@@ -58,6 +58,7 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
                  hipStream_t s) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
+    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_BF16 ? 2.0 : 4.0)), s);
     if (y_dtype == BG_BF16) {
         if (silu) hipLaunchKernelGGL((ln768_kernel<true, true>), grid, block, 0, s, x, g, b, y, M, eps);
         else hipLaunchKernelGGL((ln768_kernel<true, false>), grid, block, 0, s, x, g, b, y, M, eps);
@@ -186,6 +187,7 @@ int ddpm_step(const DdpmArgs& a, hipStream_t s) {
     if (a.n == 0) return 0;
     const bool vec = (a.n % 4 == 0) && aligned16(a.eps_c) && aligned16(a.eps_u) && aligned16(a.x) &&
                      aligned16(a.noise) && aligned16(a.out);
+    ProfScope prof(PK_DDPM_STEP, 0.0, 4.0 * a.n * (3.0 + (a.eps_u ? 1 : 0) + (a.noise ? 1 : 0)), s);
     const size_t work = vec ? a.n / 4 : a.n;
     const int grid = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
     if (vec) hipLaunchKernelGGL(ddpm_step_kernel<true>, dim3(grid), dim3(256), 0, s, a);
@@ -227,6 +229,8 @@ __global__ __launch_bounds__(256) void pndm_step_kernel(PndmArgs a) {
 int pndm_step(const PndmArgs& a, hipStream_t s) {
     if (a.n == 0) return 0;
     const int grid = (int)((a.n + 255) / 256 < 4096 ? (a.n + 255) / 256 : 4096);
+    ProfScope prof(PK_PNDM_STEP, 0.0, 4.0 * a.n * (3.0 + (a.eps_u ? 1 : 0) + (a.e_store ? 1 : 0) + (a.acc ? 1 : 0) +
+                   (a.acc_out ? 1 : 0) + (a.h0 ? 1 : 0) + (a.h1 ? 1 : 0) + (a.h2 ? 1 : 0)), s);
     hipLaunchKernelGGL(pndm_step_kernel, dim3(grid), dim3(256), 0, s, a);
     return launch_status("pndm_step");
 }

@@ -198,6 +198,11 @@ int gemm_bf16(const GemmArgs& g, hipStream_t s) {
         return BG_E_ALIGN;
     }
     const int mt = (g.M + 127) / 128;
+    // algorithmic cost: 2*M*N*K flops; bytes = operands once + output once (+ addends)
+    const double osz = g.out_dtype == BG_BF16 ? 2.0 : 4.0;
+    const double bytes = 2.0 * g.M * g.K + 2.0 * g.N * (double)g.K + osz * g.M * g.N +
+                         (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0) + (g.add2 ? 4.0 * (g.M / g.add2_div) * g.N : 0.0);
+    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, 2.0 * g.M * g.N * (double)g.K, bytes, s);
     if (g.N_pad % 128 == 0) {
         hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2>), dim3(mt * (g.N_pad / 128)), dim3(256), 0, s, g);
     } else {

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return 0;
     const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
+    const double osz = g.out_dtype == BG_BF16 ? 2.0 : 4.0;
+    ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K,
+                   4.0 * g.M * g.K + 4.0 * g.N * (double)g.K + osz * g.M * g.N + (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0), s);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(nblk), dim3(256), 0, s, g);
     return launch_status("gemm_f32");
 }

@@ -161,6 +161,21 @@ int bg_pndm_step(const float* eps_c, const float* eps_u, float guidance_w, const
                  const float* hist2, float c_h0, float c_h1, float c_h2, float sample_coeff,
                  float eps_coeff, float* out, size_t n, bg_stream_t stream);
 
+/* ---- measurement aid (bench.py's roofline leg): hipEvent pairs around every kernel launch ------------
+ * bg_profile_begin allocates up to max_launches event pairs and switches recording on (this is the one
+ * place the library owns state; it is off by default and costs nothing when off).  bg_profile_end
+ * synchronises, aggregates per kernel and frees the events.  flops / bytes are the ALGORITHMIC counts the
+ * launcher derives from the shapes (DESIGN.md "roofline accounting"). */
+typedef struct {
+    const char* kernel;     /* static string */
+    int launches;
+    double total_ms;        /* sum of launch durations */
+    double flops;           /* sum of algorithmic FLOPs */
+    double bytes;           /* sum of algorithmic HBM bytes */
+} bg_profile_row;
+int bg_profile_begin(int max_launches);
+int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number of rows written (<0: error) */
+
 /* DDPMScheduler.add_noise (training-time forward diffusion, trainer.py:348,399,515,...):
  *   out[b,:] = sqrt_alpha_prod[b] * x0[b,:] + sqrt_one_minus_alpha_prod[b] * noise[b,:]
  * the two per-sample scalar vectors are device fp32 [B] (gathered from alphas_cumprod by the host shim). */

@@ -1,0 +1,112 @@
+"""CPU-side checks of the C-ABI boundary and the host logic (no kernel is launched)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import brepgen_amd as bga
+from brepgen_amd import _lib
+from oracle import denoisers as orc
+from oracle.schedulers import OracleDDPM, OraclePNDM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "brepgen_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/brepgen_hip.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+    assert lib.bg_abi_version() == 1
+
+
+def test_argument_errors_are_negative_and_explained():
+    lib = _lib.load()
+    rc = lib.bg_gemm_bias_act_fwd(None, 0, None, None, None, 0, 1, 1, 1, 1, 0, 0, 0, None, 0, 1, None)
+    assert rc == -1 and b"null" in lib.bg_last_error()
+    rc = lib.bg_cfg_ddpm_step(None, None, 0.0, None, None, None, 0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, None)
+    assert rc == -1
+    w, i = _lib.DenoiserWeights(), _lib.DenoiserInputs()
+    w.net = 7
+    assert lib.bg_denoiser_fwd(C.byref(w), C.byref(i), None, None, 0, None) < 0
+
+
+def test_workspace_bytes_scales_with_tokens():
+    lib = _lib.load()
+    a = lib.bg_workspace_bytes(_lib.BG_SURFZ, 512, 60, 1, _lib.BG_BF16)
+    b = lib.bg_workspace_bytes(_lib.BG_SURFZ, 1024, 60, 1, _lib.BG_BF16)
+    assert 0 < a < b < 2.2 * a
+    # X fp32 + H bf16 + QKV bf16 = 3072 + 1536 + 4608 bytes per token, plus small buffers
+    assert a >= 512 * 60 * 9216
+    assert lib.bg_workspace_bytes(_lib.BG_EDGEZ, 2, 60, 30, _lib.BG_F32) > lib.bg_workspace_bytes(
+        _lib.BG_EDGEZ, 2, 60, 30, _lib.BG_BF16)
+    assert lib.bg_workspace_bytes(_lib.BG_SURFZ, 0, 60, 1, _lib.BG_BF16) == 0
+
+
+@pytest.mark.parametrize("net", ["SurfPosNet", "SurfZNet", "EdgePosNet", "EdgeZNet"])
+@pytest.mark.parametrize("use_cf", [False, True])
+def test_state_dict_keys_match_reference_layout(net, use_cf):
+    m = getattr(bga, net)(use_cf)
+    spec = orc.state_dict_spec(net, use_cf)
+    sd = m.state_dict()
+    assert set(sd) == set(spec)
+    for k, shape in spec.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    m.load_state_dict(orc.seeded_state_dict(net, 3, use_cf), strict=True)
+
+
+def test_no_cpu_fallback():
+    m = bga.SurfPosNet(False)
+    with pytest.raises(_lib.BrepgenHipError):
+        m(torch.zeros(1, 4, 6), torch.tensor([5]), None)
+    s = bga.DDPMScheduler()
+    with pytest.raises(_lib.BrepgenHipError):
+        s.step(torch.zeros(2, 3), 5, torch.zeros(2, 3))
+
+
+def test_scheduler_host_logic_matches_oracle():
+    d, o = bga.DDPMScheduler(clip_sample=True, clip_sample_range=3), OracleDDPM(clip_sample_range=3)
+    for n in (1000, 50):
+        d.set_timesteps(n)
+        o.set_timesteps(n)
+        assert d.timesteps.tolist() == o.timesteps.tolist()
+        for t in (int(d.timesteps[0]), int(d.timesteps[len(d.timesteps) // 2]), 0):
+            c, r = d._coefficients(t), o.coefficients(t)
+            assert c["x0_coeff"] == r["x0_coeff"] and c["xt_coeff"] == r["xt_coeff"] and c["sigma"] == r["sigma"]
+            assert c["sqrt_alpha_prod"] == r["sqrt_alpha_prod_t"] and c["sqrt_beta_prod"] == r["sqrt_beta_prod_t"]
+    p, q = bga.PNDMScheduler(), OraclePNDM()
+    p.set_timesteps(200)
+    q.set_timesteps(200)
+    assert p.timesteps.tolist() == q.timesteps.tolist() and len(p.timesteps) == 209
+    assert p._prev_coeffs(980, 975) == tuple(float(v) for v in q.prev_sample_coeffs(980, 975))
+    assert p._prev_coeffs(0, -5) == tuple(float(v) for v in q.prev_sample_coeffs(0, -5))
+    assert d.config.num_train_timesteps == 1000 and len(d) == 1000
+
+
+def test_randn_tensor_seed_semantics():
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    a = bga.randn_tensor((4, 30, 6), generator=g1)
+    b = torch.randn(4, 30, 6, generator=g2)
+    assert torch.equal(a, b) and a.device.type == "cpu"
+    gs = [torch.Generator().manual_seed(i) for i in range(3)]
+    c = bga.randn_tensor((3, 5), generator=gs)
+    assert torch.equal(c[1:2], torch.randn(1, 5, generator=torch.Generator().manual_seed(1)))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "brepgen_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
