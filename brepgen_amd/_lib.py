@@ -65,6 +65,7 @@ _SIGNATURES = {
                                C.c_size_t, vp]),
     "bg_profile_begin": (C.c_int, [C.c_int]),
     "bg_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int]),
+    "bg_tune_set": (C.c_int, [C.c_int, C.c_int]),
     "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -33,6 +33,10 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
     ~ProfScope() { if (g_prof_on) prof_post(k, f, b, s); }
 };
 
+// ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
+enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_COUNT = 8 };
+extern int g_tune[TUNE_COUNT];
+
 // ---- vector types -----------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -24,6 +24,8 @@ int launch_status(const char* what) {
     return (int)e;
 }
 
+int g_tune[TUNE_COUNT] = {0};
+
 // ---- per-kernel event timing ------------------------------------------------------------------------------
 bool g_prof_on = false;
 namespace {
@@ -246,6 +248,12 @@ extern "C" int bg_profile_end(bg_profile_row* rows, int max_rows) {
     for (int k = 0; k < PK_COUNT && n < max_rows; ++k)
         if (agg[k].launches > 0 && rows) rows[n++] = agg[k];
     return n;
+}
+
+extern "C" int bg_tune_set(int key, int value) {
+    BG_REQUIRE(key >= 0 && key < bg::TUNE_COUNT, BG_E_ARG, "bg_tune_set: unknown key %d", key);
+    bg::g_tune[key] = value;
+    return 0;
 }
 
 extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }

@@ -176,6 +176,9 @@ typedef struct {
 int bg_profile_begin(int max_launches);
 int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number of rows written (<0: error) */
 
+/* Kernel-selection knob for A/B measurements (key 0: bf16 GEMM tile/pipeline variant, 0 = shipped default). */
+int bg_tune_set(int key, int value);
+
 /* DDPMScheduler.add_noise (training-time forward diffusion, trainer.py:348,399,515,...):
  *   out[b,:] = sqrt_alpha_prod[b] * x0[b,:] + sqrt_one_minus_alpha_prod[b] * noise[b,:]
  * the two per-sample scalar vectors are device fp32 [B] (gathered from alphas_cumprod by the host shim). */

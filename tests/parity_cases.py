@@ -237,7 +237,7 @@ def oracle_case(net, B, S, E, dtype, use_cf=False, seed=7):
     return e
 
 
-def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3):
+def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3, last=None):
     """BASELINE configs[0]: B=1 face-LDM, `steps` DDPM steps of SurfZNet with injected noise, HIP vs oracle.
     Both chains are fed the ORACLE's trajectory (per-step parity: same x_t in, compare x_{t-1} out)."""
     m, sd = build_net("SurfZNet", seed, False, dtype)
@@ -254,7 +254,7 @@ def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3):
     worst_eps = worst_x = 0.0
     sp_d, mk_d = surfPos.to(DEV), mask.to(DEV)
     with torch.no_grad():
-        for t in s.timesteps:
+        for t in (s.timesteps if last is None else s.timesteps[-last:]):
             noise = torch.randn(B, N, 48, generator=g)
             tt = t.reshape(-1)
             eo = orc.surfz_forward(sd, x, tt, surfPos, mask)
