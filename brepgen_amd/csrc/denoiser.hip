@@ -33,7 +33,7 @@ struct ProfRec { hipEvent_t e0, e1; int kernel; double flops, bytes; };
 ProfRec* g_recs = nullptr;
 int g_cap = 0, g_n = 0;
 bool g_open = false;
-const char* const kProfNames[PK_COUNT] = {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_f32", "attn_bf16", "attn_f32",
+const char* const kProfNames[PK_COUNT] = {"gemm_bf16_p_kernel(128x128 persistent)", "gemm_bf16_128x64", "gemm_f32", "attn_bf16", "attn_f32",
                                           "layernorm768", "cfg_ddpm_step", "pndm_step", "misc"};
 }  // namespace
 

@@ -33,6 +33,9 @@ def main():
     g = torch.Generator().manual_seed(0)
     shapes = [("qkv", 2304, 768, "bf16"), ("outproj", 768, 768, "resid"), ("ffn1", 1024, 768, "bf16"),
               ("ffn2", 768, 1024, "resid")]
+    if os.environ.get("KBIG"):
+        kb = int(os.environ["KBIG"])
+        shapes = [("bigk_2304", 2304, kb, "bf16"), ("bigk_768", 768, kb, "bf16")]
     data = {}
     for name, N, K, mode in shapes:
         a = torch.randn(M, K, generator=g).cuda().to(BF16)
@@ -48,13 +51,26 @@ def main():
             o = torch.zeros_like(out)
             ops.linear(a, w, b, out=o, act=1 if name == "ffn1" else 0)
             torch.cuda.synchronize()
-            if v >= 10:
+            if 10 < v < 20 and v not in (14, 15):
                 continue
             if v == VARIANTS[0]:
                 ref[name] = o.float().clone()
             else:
                 d = float((o.float() - ref[name]).abs().max())
                 print(f"[check] variant {v} {name}: max|diff vs variant {VARIANTS[0]}| = {d:.3e}", flush=True)
+    if os.environ.get("DEPHASE"):
+        for name, (a, w, b, out, mode, N, K) in data.items():
+            line = f"[dephase] {name:8s}:"
+            lib.bg_tune_set(0, 30)
+            for d in [int(x) for x in os.environ["DEPHASE"].split(",")]:
+                lib.bg_tune_set(3, d)
+                if mode == "bf16":
+                    us = timed(lambda: ops.linear(a, w, b, out=out, act=1 if name == "ffn1" else 0))
+                else:
+                    us = timed(lambda: ops.linear(a, w, b, add=out, out=out))
+                line += f"  d{d} {us:6.1f}us"
+            print(line, flush=True)
+        lib.bg_tune_set(3, 0)
     for rnd in range(3):
         for name, (a, w, b, out, mode, N, K) in data.items():
             line = f"[round {rnd}] {name:8s} {M}x{N}x{K} {mode:5s}:"
