@@ -1,0 +1,243 @@
+// Kernels of the surface / edge VAE decoders (network.py:786-858, 948-1040 + the diffusers==0.27 decoder blocks).
+//
+// Layout: channels-last activations, fp32: 2-D [F, H, W, C], 1-D [G, L, C] (== 2-D with H = 1).  Every convolution
+// becomes  im2col (this file) -> MFMA GEMM (gemm_bf16.hip / gemm_f32.hip, bias + residual fused in its epilogue):
+//   * the GroupNorm + SiLU / GELU that precedes each conv in ResnetBlock2D / ResConvBlock is applied INSIDE the
+//     im2col gather (per-(sample, group) mean / rstd from gn_stats_kernel), so the normalised tensor never exists;
+//   * the nearest-neighbour x2 up-sampling of Upsample2D is folded into the gather as well (source index >> 1);
+//   * zero padding is applied after norm + activation, as the reference pads the activated tensor.
+// Everything here is HBM-bound (judged in GB/s); the FLOPs are in the GEMMs.
+#include "bg_common.h"
+#include <math.h>
+
+namespace bg {
+
+// ---- GroupNorm statistics: one wave per (sample, group), two passes (mean, centred variance) ----------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int S, int P,
+                                                       int C, int G, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= S * G) return;
+    const int s = id / G, g = id % G;
+    const int cpg = C / G, q4 = cpg >> 2;                 // float4 per position
+    const int n4 = P * q4;
+    const float* base = x + (size_t)s * P * C + g * cpg;
+    float sum = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const int p = i / q4, c4 = i - p * q4;
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C + c4 * 4);
+        sum += (v.x + v.y) + (v.z + v.w);
+    }
+    const float inv_n = 1.0f / (float)(P * cpg);
+    const float mean = wave_sum(sum) * inv_n;
+    float var = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const int p = i / q4, c4 = i - p * q4;
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * C + c4 * 4);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        var += (a * a + b * b) + (c * c + d * d);
+    }
+    var = wave_sum(var) * inv_n;
+    if (lane == 0) {
+        stats[(size_t)id * 2 + 0] = mean;
+        stats[(size_t)id * 2 + 1] = 1.0f / sqrtf(var + eps);
+    }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return silu_f(v);
+    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));    // nn.GELU() (erf form)
+    return v;
+}
+
+struct Im2colArgs {
+    const float* x; void* out; int out_bf16;
+    int S, Hin, Win, C, kh, kw, up;
+    const float* stats; const float* gamma; const float* beta; int G; int act;
+    const float* add;        // optional residual, added after norm + activation (1x1 / fp32-out use only)
+};
+
+// one thread = 4 consecutive channels of one (row, tap)
+__global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
+    const int H = a.Hin << a.up, W = a.Win << a.up;
+    const int c4n = a.C >> 2, taps = a.kh * a.kw;
+    const size_t total = (size_t)a.S * H * W * taps * c4n;
+    const int ph = a.kh >> 1, pw = a.kw >> 1;
+    const int cpg = a.stats ? a.C / a.G : 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int tap = (int)(r % taps);
+        r /= taps;                                            // row = (s, oy, ox)
+        const int ox = (int)(r % W);
+        const size_t r2 = r / W;
+        const int oy = (int)(r2 % H), s = (int)(r2 / H);
+        const int iy = oy + tap / a.kw - ph, ix = ox + tap % a.kw - pw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const int c = c4 * 4;
+            v = *reinterpret_cast<const float4*>(a.x + (((size_t)s * a.Hin + (iy >> a.up)) * a.Win + (ix >> a.up)) * a.C + c);
+            if (a.stats) {
+                const int g = c / cpg;                        // cpg % 4 == 0: the 4 channels share a group
+                const float mean = a.stats[((size_t)s * a.G + g) * 2], rstd = a.stats[((size_t)s * a.G + g) * 2 + 1];
+                const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
+                const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+                v.x = (v.x - mean) * rstd * ga.x + be.x;
+                v.y = (v.y - mean) * rstd * ga.y + be.y;
+                v.z = (v.z - mean) * rstd * ga.z + be.z;
+                v.w = (v.w - mean) * rstd * ga.w + be.w;
+            }
+            v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act);
+            v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act);
+        }
+        const size_t o = (r * taps + tap) * (size_t)a.C + c4 * 4;
+        if (a.add) {
+            const float4 ad = *reinterpret_cast<const float4*>(a.add + o);
+            v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+        }
+        if (a.out_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + o) = to_bf16x4(v.x, v.y, v.z, v.w);
+        else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = v;
+    }
+}
+
+// any C (the 3-channel latent inputs of post_quant_conv / conv_in), no norm, fp32 out
+__global__ __launch_bounds__(256) void im2col_scalar_kernel(Im2colArgs a) {
+    const int H = a.Hin << a.up, W = a.Win << a.up, taps = a.kh * a.kw;
+    const size_t total = (size_t)a.S * H * W * taps * a.C;
+    const int ph = a.kh >> 1, pw = a.kw >> 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % a.C);
+        size_t r = i / a.C;
+        const int tap = (int)(r % taps);
+        r /= taps;
+        const int ox = (int)(r % W);
+        const size_t r2 = r / W;
+        const int oy = (int)(r2 % H), s = (int)(r2 / H);
+        const int iy = oy + tap / a.kw - ph, ix = ox + tap % a.kw - pw;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = act_apply(a.x[(((size_t)s * a.Hin + (iy >> a.up)) * a.Win + (ix >> a.up)) * a.C + c], a.act);
+        if (a.out_bf16) reinterpret_cast<__bf16*>(a.out)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(a.out)[i] = v;
+    }
+}
+
+// ---- Upsample1d("cubic"): reflect-pad 2, stride-2 transposed conv with the 8-tap kernel x2, padding 7 ----------
+// written as the equivalent 4-tap depthwise gather: y[o] = sum_i hp[i] * w[o + 7 - 2i], hp[i] = x[reflect(i - 2)]
+__constant__ float kCubic2[8] = {-0.0234375f, -0.0703125f, 0.2265625f, 0.8671875f, 0.8671875f, 0.2265625f, -0.0703125f, -0.0234375f};
+
+__global__ __launch_bounds__(256) void upsample1d_cubic_kernel(const float* __restrict__ x, float* __restrict__ y, int S, int L,
+                                                               int C) {
+    const size_t total = (size_t)S * 2 * L * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int o = (int)(r % (2 * L)), s = (int)(r / (2 * L));
+        float acc = 0.f;
+        const int i0 = (o + 1) >> 1, i1 = (o + 7) >> 1;
+        for (int ii = i0; ii <= i1; ++ii) {
+            const int kk = o + 7 - 2 * ii;
+            if (kk < 0 || kk > 7 || ii > L + 3) continue;
+            int j = ii - 2;
+            j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);
+            acc = fmaf(x[((size_t)s * L + j) * C + c], kCubic2[kk], acc);
+        }
+        y[i] = acc;
+    }
+}
+
+// ---- tiny self-attention of the VAE mid blocks: T tokens (16 for the 4x4 surface latent, 4 for the edge latent),
+// nh heads; one workgroup per sample; fp32 math.  qkv: [S*T, ld] with q | k | v at column offsets 0, C, 2C. ----
+__global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict__ qkv, int ld, void* __restrict__ out,
+                                                         int out_bf16, int T, int C, int nh, float scale) {
+    extern __shared__ float sc[];                           // [nh][T][T]
+    const int s = blockIdx.x, d = C / nh, n_sc = nh * T * T;
+    const float* base = qkv + (size_t)s * T * ld;
+    for (int e = threadIdx.x; e < n_sc; e += blockDim.x) {
+        const int j = e % T, i = (e / T) % T, hh = e / (T * T);
+        const float* q = base + (size_t)i * ld + hh * d;
+        const float* k = base + (size_t)j * ld + C + hh * d;
+        float acc = 0.f;
+        for (int t = 0; t < d; ++t) acc = fmaf(q[t], k[t], acc);
+        sc[e] = acc * scale;
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < nh * T; row += blockDim.x) {
+        float* p = sc + (size_t)row * T;
+        float m = -INFINITY;
+        for (int j = 0; j < T; ++j) m = fmaxf(m, p[j]);
+        float l = 0.f;
+        for (int j = 0; j < T; ++j) { p[j] = expf(p[j] - m); l += p[j]; }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < T; ++j) p[j] *= inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * C; e += blockDim.x) {
+        const int col = e % C, i = e / C, hh = col / d;
+        const float* p = sc + ((size_t)hh * T + i) * T;
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc = fmaf(p[j], base[(size_t)j * ld + 2 * C + col], acc);
+        const size_t o = ((size_t)s * T + i) * C + col;
+        if (out_bf16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)acc;
+        else reinterpret_cast<float*>(out)[o] = acc;
+    }
+}
+
+static inline int cap_grid(size_t work) {
+    const size_t b = (work + 255) / 256;
+    return (int)(b < 8192 ? (b ? b : 1) : 8192);
+}
+
+}  // namespace bg
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------
+extern "C" int bg_groupnorm_stats(const float* x, float* stats, int S, int P, int C, int G, float eps, bg_stream_t stream) {
+    BG_REQUIRE(x && stats, BG_E_ARG, "bg_groupnorm_stats: null pointer");
+    BG_REQUIRE(S > 0 && P > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0, BG_E_SHAPE,
+               "bg_groupnorm_stats: need C %% G == 0 and (C/G) %% 4 == 0 (S=%d P=%d C=%d G=%d)", S, P, C, G);
+    bg::ProfScope prof(bg::PK_MISC, 0.0, 8.0 * S * (double)P * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bg::gn_stats_kernel, dim3((S * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, stats, S, P, C, G, eps);
+    return bg::launch_status("groupnorm_stats");
+}
+
+extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hin, int Win, int C, int kh, int kw, int up,
+                         const float* stats, const float* gamma, const float* beta, int G, int act, const float* add,
+                         bg_stream_t stream) {
+    BG_REQUIRE(x && out, BG_E_ARG, "bg_im2col: null pointer");
+    BG_REQUIRE(S > 0 && Hin > 0 && Win > 0 && C > 0 && (kh & 1) && (kw & 1) && (up == 0 || up == 1), BG_E_SHAPE,
+               "bg_im2col: bad shape");
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_im2col: out dtype %d", out_dtype);
+    BG_REQUIRE(stats == nullptr || (gamma && beta && G > 0 && C % G == 0 && (C / G) % 4 == 0), BG_E_ARG,
+               "bg_im2col: normalisation needs gamma, beta and (C/G) %% 4 == 0");
+    BG_REQUIRE(add == nullptr || (kh == 1 && kw == 1 && C % 4 == 0), BG_E_ARG, "bg_im2col: residual add needs a 1x1 window");
+    bg::Im2colArgs a{x, out, out_dtype == BG_BF16, S, Hin, Win, C, kh, kw, up, stats, gamma, beta, G, act, add};
+    const size_t rows = (size_t)S * (Hin << up) * (Win << up);
+    bg::ProfScope prof(bg::PK_MISC, 0.0, rows * (double)kh * kw * C * (4.0 + (out_dtype == BG_BF16 ? 2.0 : 4.0)),
+                       (hipStream_t)stream);
+    if (C % 4 == 0) {
+        hipLaunchKernelGGL(bg::im2col_kernel, dim3(bg::cap_grid(rows * kh * kw * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        BG_REQUIRE(stats == nullptr, BG_E_SHAPE, "bg_im2col: normalised input needs C %% 4 == 0");
+        hipLaunchKernelGGL(bg::im2col_scalar_kernel, dim3(bg::cap_grid(rows * kh * kw * C)), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return bg::launch_status("im2col");
+}
+
+extern "C" int bg_upsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream) {
+    BG_REQUIRE(x && y && S > 0 && L >= 3 && C > 0, BG_E_ARG, "bg_upsample1d_cubic: bad arguments (reflect pad needs L >= 3)");
+    bg::ProfScope prof(bg::PK_MISC, 0.0, 12.0 * S * (double)L * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bg::upsample1d_cubic_kernel, dim3(bg::cap_grid((size_t)S * 2 * L * C)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, S, L, C);
+    return bg::launch_status("upsample1d_cubic");
+}
+
+extern "C" int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype, int S, int T, int C, int nh, float scale,
+                             bg_stream_t stream) {
+    BG_REQUIRE(qkv && out && S > 0 && T > 0 && nh > 0 && C % nh == 0 && ld >= 3 * C, BG_E_ARG, "bg_small_attn: bad arguments");
+    BG_REQUIRE(nh * T * T <= 8192, BG_E_SHAPE, "bg_small_attn: nh*T*T = %d exceeds the LDS score buffer", nh * T * T);
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_small_attn: out dtype %d", out_dtype);
+    bg::ProfScope prof(bg::PK_MISC, 4.0 * S * (double)T * T * C, 16.0 * S * (double)T * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bg::small_attn_kernel, dim3(S), dim3(256), (size_t)nh * T * T * sizeof(float), (hipStream_t)stream, qkv, ld,
+                       out, out_dtype == BG_BF16, T, C, nh, scale);
+    return bg::launch_status("small_attn");
+}

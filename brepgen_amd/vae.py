@@ -1,0 +1,408 @@
+"""Drop-in mirrors of the two VAE *decoders* BrepGen samples with, on the HIP path.
+
+``AutoencoderKLFastDecode`` (network.py:948-1040, built at sample.py:72-84) and ``AutoencoderKL1DFastDecode``
+(network.py:786-858, built at sample.py:86-99): same constructor keywords, same ``forward(z)`` -> decoded points,
+and the diffusers checkpoint key layout, so ``load_state_dict(torch.load(vae.pt), strict=False)`` works as at
+sample.py:83,98 (the file also holds ``encoder.*`` / ``quant_conv.*``, which are ignored).
+
+Execution: channels-last fp32 activations; every convolution = ``bg_im2col`` (GroupNorm + SiLU/GELU and the nearest
+x2 up-sampling folded into the gather) + the MFMA GEMM with bias / residual fused in its epilogue; mid-block
+attention = one fused q|k|v GEMM + ``bg_small_attn`` + projection GEMM; ``Upsample1d("cubic")`` = ``bg_upsample1d_cubic``.
+The nn.Module tree below only holds parameters.  Like the denoisers, bf16 operands inside autocast, exact fp32 outside.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import BG_BF16, BG_F32, check, ptr, stream
+
+CUBIC2 = [2 * v for v in (-0.01171875, -0.03515625, 0.11328125, 0.43359375, 0.43359375, 0.11328125, -0.03515625,
+                          -0.01171875)]
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers (diffusers key layout)
+# --------------------------------------------------------------------------------------------------
+class _Resnet2D(nn.Module):
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            self.conv_shortcut = nn.Conv2d(cin, cout, 1)
+
+
+class _Attn2D(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, c, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+
+class _Up2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+
+class _UpBlock2D(nn.Module):
+    def __init__(self, cin, cout, n, groups, upsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet2D(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        if upsample:
+            self.upsamplers = nn.ModuleList([_Up2D(cout)])
+
+
+class _Mid2D(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.attentions = nn.ModuleList([_Attn2D(c, groups)])
+        self.resnets = nn.ModuleList([_Resnet2D(c, c, groups), _Resnet2D(c, c, groups)])
+
+
+class _Decoder2D(nn.Module):
+    def __init__(self, latent, out_ch, block_out, layers_per_block, groups):
+        super().__init__()
+        top = block_out[-1]
+        self.conv_in = nn.Conv2d(latent, top, 3, padding=1)
+        self.mid_block = _Mid2D(top, groups)
+        rev = list(reversed(block_out))
+        blocks, prev = [], rev[0]
+        for i, ch in enumerate(rev):
+            blocks.append(_UpBlock2D(prev, ch, layers_per_block + 1, groups, upsample=i != len(rev) - 1))
+            prev = ch
+        self.up_blocks = nn.ModuleList(blocks)
+        self.conv_norm_out = nn.GroupNorm(groups, block_out[0], eps=1e-6)
+        self.conv_out = nn.Conv2d(block_out[0], out_ch, 3, padding=1)
+
+
+class _ResConv(nn.Module):
+    def __init__(self, cin, mid, cout):
+        super().__init__()
+        if cin != cout:
+            self.conv_skip = nn.Conv1d(cin, cout, 1, bias=False)
+        self.conv_1 = nn.Conv1d(cin, mid, 5, padding=2)
+        self.group_norm_1 = nn.GroupNorm(1, mid)
+        self.conv_2 = nn.Conv1d(mid, cout, 5, padding=2)
+        self.group_norm_2 = nn.GroupNorm(1, cout)
+
+
+class _Attn1D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(1, c)
+        self.query, self.key, self.value, self.proj_attn = (nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c),
+                                                            nn.Linear(c, c))
+
+
+class _Cubic(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("kernel", torch.tensor(CUBIC2))
+
+
+class _UpBlock1D(nn.Module):                       # network.py:30-48
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.resnets = nn.ModuleList([_ResConv(cin, cin, cin), _ResConv(cin, cin, cin), _ResConv(cin, cin, cout)])
+        self.up = _Cubic()
+
+
+class _Mid1D(nn.Module):                           # network.py:51-83
+    def __init__(self, c):
+        super().__init__()
+        self.attentions = nn.ModuleList([_Attn1D(c) for _ in range(6)])
+        self.resnets = nn.ModuleList([_ResConv(c, c, c) for _ in range(6)])
+
+
+class _Decoder1D(nn.Module):                       # network.py:188-244
+    def __init__(self, latent, out_ch, block_out, groups):
+        super().__init__()
+        top = block_out[-1]
+        self.conv_in = nn.Conv1d(latent, top, 3, padding=1)
+        self.mid_block = _Mid1D(top)
+        rev = list(reversed(block_out))
+        blocks, prev = [], rev[0]
+        for ch in rev:
+            blocks.append(_UpBlock1D(prev, ch))
+            prev = ch
+        self.up_blocks = nn.ModuleList(blocks)
+        self.conv_norm_out = nn.GroupNorm(groups, block_out[0], eps=1e-6)
+        self.conv_out = nn.Conv1d(block_out[0], out_ch, 3, padding=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# execution helpers
+# --------------------------------------------------------------------------------------------------
+class _Packed:
+    """One convolution / linear as a GEMM: weight [n_pad, K] (compute dtype, or fp32 when K % 64 != 0), fp32 bias."""
+    __slots__ = ("w", "b", "n", "k", "dtype")
+
+
+class _HipVAE(nn.Module):
+    IM2COL_BUDGET = 1 << 30        # bytes of im2col scratch per chunk of samples
+
+    def __init__(self):
+        super().__init__()
+        self.compute_dtype = None
+        self._packs = {}
+
+    def _apply(self, fn, *a, **k):
+        self._packs = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packs = {}
+        return super().load_state_dict(*a, **k)
+
+    def _dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    # ---- packing ----
+    @staticmethod
+    def _pack_gemm(weight2d, bias, dt):
+        n, k = weight2d.shape
+        p = _Packed()
+        use = dt if (dt == torch.float32 or k % 64 == 0) else torch.float32
+        w = weight2d.detach().to(torch.float32)
+        pad = 64 if use == torch.bfloat16 else 1
+        if n % pad:
+            w = torch.cat([w, w.new_zeros((-n) % pad, k)])
+        p.w = w.to(use).contiguous()
+        b = torch.zeros(n, device=w.device) if bias is None else bias.detach().to(torch.float32)
+        if b.numel() % pad:
+            b = torch.cat([b, b.new_zeros((-b.numel()) % pad)])
+        p.b, p.n, p.k, p.dtype = b.contiguous(), n, k, use
+        return p
+
+    def _pack_conv(self, conv, dt):
+        w = conv.weight.detach()
+        if w.dim() == 3:                               # Conv1d [Cout, Cin, k] -> [Cout, k*Cin] (tap-major)
+            w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)
+        else:                                          # Conv2d [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
+            w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        return self._pack_gemm(w2, conv.bias, dt)
+
+    # ---- primitive steps on channels-last fp32 tensors [S, H, W, C] ----
+    def _stats(self, x, S, P, C, norm):
+        st = torch.empty(S, norm.num_groups, 2, device=x.device, dtype=torch.float32)
+        check(_lib.load().bg_groupnorm_stats(ptr(x), ptr(st), S, P, C, norm.num_groups, norm.eps, stream()),
+              "bg_groupnorm_stats")
+        return st
+
+    def _conv(self, x, shape, pk, kh, kw, up=0, norm=None, act=ACT_NONE, residual=None):
+        S, H, W, C = shape
+        lib = _lib.load()
+        Ho, Wo = H << up, W << up
+        rows = S * Ho * Wo
+        a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
+        st = self._stats(x, S, H * W, C, norm) if norm is not None else None
+        g = norm.weight.detach().float().contiguous() if norm is not None else None
+        b = norm.bias.detach().float().contiguous() if norm is not None else None
+        check(lib.bg_im2col(ptr(x), ptr(a), BG_BF16 if pk.dtype == torch.bfloat16 else BG_F32, S, H, W, C, kh, kw, up,
+                            ptr(st), ptr(g), ptr(b), norm.num_groups if norm is not None else 1, act, None, stream()),
+              "bg_im2col")
+        out = ops.linear(a, pk.w, pk.b, out_dtype=torch.float32, add=residual, add_div=1, n_valid=pk.n)
+        return out, (S, Ho, Wo, pk.n)
+
+    def _chunk(self, n, per_sample_bytes):
+        return max(1, min(n, self.IM2COL_BUDGET // max(1, per_sample_bytes)))
+
+
+class AutoencoderKLFastDecode(_HipVAE):
+    """Surface-VAE decoder: z [F,3,4,4] -> points [F,3,32,32]  (network.py:948-1040)."""
+
+    def __init__(self, in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",),
+                 up_block_types=("UpDecoderBlock2D",), block_out_channels=(64,), layers_per_block=1, act_fn="silu",
+                 latent_channels=4, norm_num_groups=32, sample_size=32, scaling_factor=0.18215, force_upcast=True):
+        super().__init__()
+        if act_fn != "silu":
+            raise NotImplementedError("BrepGen builds its VAEs with act_fn='silu'")
+        self.block_out = tuple(block_out_channels)
+        self.groups, self.latent, self.out_ch = norm_num_groups, latent_channels, out_channels
+        self.decoder = _Decoder2D(latent_channels, out_channels, self.block_out, layers_per_block, norm_num_groups)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+
+    def _pack(self, dt):
+        if dt in self._packs:
+            return self._packs[dt]
+        P = {}
+        d = self.decoder
+        P["pq"] = self._pack_conv(self.post_quant_conv, dt)
+        P["in"] = self._pack_conv(d.conv_in, dt)
+
+        def resnet(name, r):
+            P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv1, dt), self._pack_conv(r.conv2, dt)
+            if hasattr(r, "conv_shortcut"):
+                P[name + "sc"] = self._pack_conv(r.conv_shortcut, dt)
+
+        resnet("m0", d.mid_block.resnets[0])
+        resnet("m1", d.mid_block.resnets[1])
+        at = d.mid_block.attentions[0]
+        P["qkv"] = self._pack_gemm(torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight]),
+                                   torch.cat([at.to_q.bias, at.to_k.bias, at.to_v.bias]), dt)
+        P["proj"] = self._pack_gemm(at.to_out[0].weight, at.to_out[0].bias, dt)
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                resnet(f"u{bi}r{ri}", r)
+            if hasattr(blk, "upsamplers"):
+                P[f"u{bi}up"] = self._pack_conv(blk.upsamplers[0].conv, dt)
+        P["out"] = self._pack_conv(d.conv_out, dt)
+        self._packs[dt] = P
+        return P
+
+    def _resnet(self, x, shape, P, name, r):
+        S, H, W, C = shape
+        h, hs = self._conv(x, shape, P[name + "c1"], 3, 3, norm=r.norm1, act=ACT_SILU)
+        if name + "sc" in P:
+            x, _ = self._conv(x, shape, P[name + "sc"], 1, 1)
+        out, os_ = self._conv(h, hs, P[name + "c2"], 3, 3, norm=r.norm2, act=ACT_SILU, residual=x)
+        return out, os_
+
+    def _decode_chunk(self, z_cl, dt):
+        """z_cl: channels-last fp32 [S,4,4,latent] -> [S,32,32,out]."""
+        P = self._pack(dt)
+        d = self.decoder
+        S = z_cl.shape[0]
+        shape = (S, z_cl.shape[1], z_cl.shape[2], self.latent)
+        x, shape = self._conv(z_cl, shape, P["pq"], 1, 1)
+        x, shape = self._conv(x, shape, P["in"], 3, 3)
+        x, shape = self._resnet(x, shape, P, "m0", d.mid_block.resnets[0])
+        # mid-block attention (1 head over H*W tokens, dim_head = C)
+        at = d.mid_block.attentions[0]
+        S_, H, W, C = shape
+        qkv, _ = self._conv(x, shape, P["qkv"], 1, 1, norm=at.group_norm)
+        o = torch.empty(S_ * H * W, C, device=x.device, dtype=P["proj"].dtype)
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), BG_BF16 if o.dtype == torch.bfloat16 else BG_F32, S_,
+                                        H * W, C, 1, 1.0 / math.sqrt(C), stream()), "bg_small_attn")
+        x = ops.linear(o, P["proj"].w, P["proj"].b, out_dtype=torch.float32, add=x, n_valid=C)
+        x, shape = self._resnet(x, shape, P, "m1", d.mid_block.resnets[1])
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x, shape = self._resnet(x, shape, P, f"u{bi}r{ri}", r)
+            if hasattr(blk, "upsamplers"):
+                x, shape = self._conv(x, shape, P[f"u{bi}up"], 3, 3, up=1)
+        x, shape = self._conv(x, shape, P["out"], 3, 3, norm=d.conv_norm_out, act=ACT_SILU)
+        return x.reshape(shape)
+
+    def forward(self, z, return_dict=True, generator=None):
+        if not z.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
+        dt = self._dtype()
+        z_cl = z.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        n = z_cl.shape[0]
+        side = z_cl.shape[1] * 2 ** (len(self.block_out) - 1)
+        worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (2 if dt == torch.bfloat16 else 4)
+        step = self._chunk(n, worst)
+        outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
+        out = torch.cat(outs) if len(outs) > 1 else outs[0]
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
+class AutoencoderKL1DFastDecode(_HipVAE):
+    """Edge-VAE decoder: z [G,3,4] -> points [G,3,32]  (network.py:786-858)."""
+
+    def __init__(self, in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",),
+                 up_block_types=("UpDecoderBlock2D",), block_out_channels=(64,), layers_per_block=1, act_fn="silu",
+                 latent_channels=4, norm_num_groups=32, sample_size=32, scaling_factor=0.18215):
+        super().__init__()
+        self.block_out = tuple(block_out_channels)
+        self.groups, self.latent, self.out_ch = norm_num_groups, latent_channels, out_channels
+        self.decoder = _Decoder1D(latent_channels, out_channels, self.block_out, norm_num_groups)
+        self.post_quant_conv = nn.Conv1d(latent_channels, latent_channels, 1)
+
+    def _pack(self, dt):
+        if dt in self._packs:
+            return self._packs[dt]
+        P = {}
+        d = self.decoder
+        P["pq"] = self._pack_conv(self.post_quant_conv, dt)
+        P["in"] = self._pack_conv(d.conv_in, dt)
+
+        def resconv(name, r):
+            P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv_1, dt), self._pack_conv(r.conv_2, dt)
+            if hasattr(r, "conv_skip"):
+                P[name + "sk"] = self._pack_conv(r.conv_skip, dt)
+
+        for i in range(6):
+            resconv(f"m{i}", d.mid_block.resnets[i])
+            at = d.mid_block.attentions[i]
+            P[f"a{i}qkv"] = self._pack_gemm(torch.cat([at.query.weight, at.key.weight, at.value.weight]),
+                                            torch.cat([at.query.bias, at.key.bias, at.value.bias]), dt)
+            P[f"a{i}proj"] = self._pack_gemm(at.proj_attn.weight, at.proj_attn.bias, dt)
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                resconv(f"u{bi}r{ri}", r)
+        P["out"] = self._pack_conv(d.conv_out, dt)
+        self._packs[dt] = P
+        return P
+
+    def _resconv(self, x, shape, P, name, r):
+        # ResConvBlock: conv k5 -> GroupNorm(1) -> GELU -> conv k5 -> GroupNorm(1) -> GELU, + (1x1) skip.
+        # group_norm_1 + GELU fold into the gather of conv_2; the trailing group_norm_2 + GELU cannot fold into the
+        # next consumer (the residual add sits in between), so it is one 1x1 "im2col" pass with the add fused.
+        h, hs = self._conv(x, shape, P[name + "c1"], 1, 5)
+        h, hs = self._conv(h, hs, P[name + "c2"], 1, 5, norm=r.group_norm_1, act=ACT_GELU)
+        S, H, W, C = hs
+        res = x
+        if name + "sk" in P:
+            res, _ = self._conv(x, shape, P[name + "sk"], 1, 1)
+        st = self._stats(h, S, H * W, C, r.group_norm_2)
+        y = torch.empty(S * H * W, C, device=h.device, dtype=torch.float32)
+        check(_lib.load().bg_im2col(ptr(h), ptr(y), BG_F32, S, H, W, C, 1, 1, 0, ptr(st),
+                                    ptr(r.group_norm_2.weight.detach().float().contiguous()),
+                                    ptr(r.group_norm_2.bias.detach().float().contiguous()), 1, ACT_GELU,
+                                    ptr(res.contiguous()), stream()),
+              "bg_im2col[norm+gelu+residual]")
+        return y, hs
+
+    def _attn(self, x, shape, P, i, at):
+        S, H, W, C = shape
+        qkv, _ = self._conv(x, shape, P[f"a{i}qkv"], 1, 1, norm=at.group_norm)
+        nh = C // 32
+        pk = P[f"a{i}proj"]
+        o = torch.empty(S * W, C, device=x.device, dtype=pk.dtype)
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), BG_BF16 if o.dtype == torch.bfloat16 else BG_F32, S,
+                                        H * W, C, nh, 1.0 / math.sqrt(C // nh), stream()), "bg_small_attn")
+        return ops.linear(o, pk.w, pk.b, out_dtype=torch.float32, add=x, n_valid=C)
+
+    def _decode_chunk(self, z_cl, dt):
+        P = self._pack(dt)
+        d = self.decoder
+        S, L = z_cl.shape[0], z_cl.shape[1]
+        shape = (S, 1, L, self.latent)
+        x, shape = self._conv(z_cl, shape, P["pq"], 1, 1)
+        x, shape = self._conv(x, shape, P["in"], 1, 3)
+        for i in range(6):
+            x, shape = self._resconv(x, shape, P, f"m{i}", d.mid_block.resnets[i])
+            x = self._attn(x, shape, P, i, d.mid_block.attentions[i])
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x, shape = self._resconv(x, shape, P, f"u{bi}r{ri}", r)
+            S_, _, L_, C = shape
+            y = torch.empty(S_ * 2 * L_, C, device=x.device, dtype=torch.float32)
+            check(_lib.load().bg_upsample1d_cubic(ptr(x), ptr(y), S_, L_, C, stream()), "bg_upsample1d_cubic")
+            x, shape = y, (S_, 1, 2 * L_, C)
+        x, shape = self._conv(x, shape, P["out"], 1, 3, norm=d.conv_norm_out, act=ACT_SILU)
+        return x.reshape(shape[0], shape[2], shape[3])
+
+    def forward(self, z, return_dict=True):
+        if not z.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
+        dt = self._dtype()
+        z_cl = z.detach().to(torch.float32).permute(0, 2, 1).contiguous()          # [G, L, 3]
+        n = z_cl.shape[0]
+        length = z_cl.shape[1] * 2 ** len(self.block_out)
+        worst = length * 5 * self.block_out[-1] * (2 if dt == torch.bfloat16 else 4)
+        step = self._chunk(n, worst)
+        outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
+        out = torch.cat(outs) if len(outs) > 1 else outs[0]
+        return out.permute(0, 2, 1).contiguous()

@@ -161,6 +161,32 @@ int bg_pndm_step(const float* eps_c, const float* eps_u, float guidance_w, const
                  const float* hist2, float c_h0, float c_h1, float c_h2, float sample_coeff,
                  float eps_coeff, float* out, size_t n, bg_stream_t stream);
 
+/* ---- VAE decoders (AutoencoderKLFastDecode / AutoencoderKL1DFastDecode, network.py:786-858, 948-1040; blocks from
+ * diffusers==0.27).  Channels-last fp32 activations [S, H, W, C] (1-D: H = 1).  A convolution is bg_im2col followed
+ * by bg_gemm_bias_act_fwd on weights reshaped to [C_out, kh*kw*C_in]. ------------------------------------------ */
+
+/* nn.GroupNorm statistics: stats[s, g] = (mean, 1/sqrt(var + eps)) over the P positions x C/G channels of group g. */
+int bg_groupnorm_stats(const float* x, float* stats /*[S,G,2]*/, int S, int P, int C, int G, float eps,
+                       bg_stream_t stream);
+
+/* im2col of a (kh x kw, stride 1, zero-pad kh/2, kw/2) convolution over the grid (Hin << up, Win << up), with
+ *   - optional nearest x2 up-sampling of the source (Upsample2D) folded in (up = 1),
+ *   - optional GroupNorm (stats from bg_groupnorm_stats, gamma, beta) and activation (0 none, 1 SiLU, 2 GELU-erf)
+ *     applied on the fly (ResnetBlock2D / ResConvBlock / conv_norm_out),
+ *   - optional residual `add` [S*H*W, C] added after the activation (1x1 window only: the tail of ResConvBlock).
+ * out: [S*H*W, kh*kw*C] fp32 or bf16, tap-major / channel-minor. */
+int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hin, int Win, int C, int kh, int kw, int up,
+              const float* stats, const float* gamma, const float* beta, int G, int act, const float* add,
+              bg_stream_t stream);
+
+/* diffusers Upsample1d("cubic") (network.py:43): x [S,L,C] -> y [S,2L,C], reflect pad + 8-tap transposed conv. */
+int bg_upsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream);
+
+/* Self-attention of the VAE mid blocks (diffusers Attention with 1 head over 16 tokens; SelfAttention1d with
+ * C/32 heads over 4 tokens): qkv fp32 [S*T, ld] with q|k|v at columns 0, C, 2C; out [S*T, C] fp32 or bf16. */
+int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype, int S, int T, int C, int nh, float scale,
+                  bg_stream_t stream);
+
 /* ---- measurement aid (bench.py's roofline leg): hipEvent pairs around every kernel launch ------------
  * bg_profile_begin allocates up to max_launches event pairs and switches recording on (this is the one
  * place the library owns state; it is off by default and costs nothing when off).  bg_profile_end

@@ -265,3 +265,49 @@ def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3, last=None):
             worst_x = max(worst_x, float((xh.cpu() - xo)[~mask].abs().max()))
             x = xo
     return {"max_abs_eps": worst_eps, "max_abs_x": worst_x, "finite": bool(torch.isfinite(xh).all())}
+
+
+# ---------------------------------------------------------------------------------------------------
+SURF_CFG = dict(in_channels=3, out_channels=3, down_block_types=["DownEncoderBlock2D"] * 4,
+                up_block_types=["UpDecoderBlock2D"] * 4, block_out_channels=[128, 256, 512, 512], layers_per_block=2,
+                act_fn="silu", latent_channels=3, norm_num_groups=32, sample_size=512)          # sample.py:72-82
+EDGE_CFG = dict(in_channels=3, out_channels=3, down_block_types=["DownBlock1D"] * 3, up_block_types=["UpBlock1D"] * 3,
+                block_out_channels=[128, 256, 512], layers_per_block=2, act_fn="silu", latent_channels=3,
+                norm_num_groups=32, sample_size=512)                                            # sample.py:86-97
+
+
+def vae_case(kind, n, dtype, seed=0):
+    """HIP VAE decoder vs the oracle restatement (oracle/vae.py) on seeded weights and latents."""
+    from oracle import vae as ov
+    g = gen(100 + seed)
+    if kind == "surf":
+        sd = ov.seeded_state_dict(ov.surf_decoder_spec(), 31 + seed)
+        m = bga.AutoencoderKLFastDecode(**SURF_CFG)
+        z = torch.randn(n, 3, 4, 4, generator=g)
+        with torch.no_grad():
+            want = ov.surf_decode(sd, z)
+    else:
+        sd = ov.seeded_state_dict(ov.edge_decoder_spec(), 41 + seed)
+        m = bga.AutoencoderKL1DFastDecode(**EDGE_CFG)
+        z = torch.randn(n, 3, 4, generator=g)
+        with torch.no_grad():
+            want = ov.edge_decode(sd, z)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.compute_dtype = dtype
+    with torch.no_grad():
+        got = m(z.to(DEV))
+    assert got.shape == want.shape
+    return _err(got, want)
+
+
+def upsample1d_case(S=3, L=8, C=12):
+    from oracle import vae as ov
+    from brepgen_amd import _lib
+    g = gen(5)
+    x = torch.randn(S, C, L, generator=g)
+    want = ov.upsample1d_cubic(x)                                  # [S, C, 2L]
+    xc = x.permute(0, 2, 1).contiguous().to(DEV)
+    y = torch.empty(S, 2 * L, C, device=DEV)
+    _lib.check(_lib.load().bg_upsample1d_cubic(xc.data_ptr(), y.data_ptr(), S, L, C, _lib.stream()), "upsample")
+    return _err(y.permute(0, 2, 1), want)

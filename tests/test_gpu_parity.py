@@ -187,3 +187,39 @@ def test_full_size_properties(pc):
                     args[3][b:b + 1].contiguous(), None)
             valid = ~args[3][b]
             assert float((one[0] - full[b])[valid].abs().max()) < 1e-6     # bit-stable across batch sizes
+
+
+# ---- VAE decoders (oracle parity-unpinned: diffusers blocks restated, see oracle/vae.py) ---------------------------
+def test_upsample1d_cubic(pc):
+    assert pc.upsample1d_case()["max_abs"] < 1e-5
+    assert pc.upsample1d_case(S=2, L=4, C=512)["max_abs"] < 1e-5
+
+
+@pytest.mark.parametrize("kind,n", [("surf", 3), ("edge", 7)])
+def test_vae_decode_fp32(pc, kind, n):
+    e = pc.vae_case(kind, n, F32)
+    assert e["finite"] and e["max_abs"] < 2e-4 * max(1.0, e["ref_absmax"])
+
+
+@pytest.mark.parametrize("kind,n", [("surf", 3), ("edge", 7)])
+def test_vae_decode_bf16(pc, kind, n):
+    e = pc.vae_case(kind, n, BF16)
+    assert e["finite"] and e["max_abs"] < 0.15 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.03
+
+
+def test_vae_decode_batch_independence(pc):
+    """Chunked execution: a large batch equals the per-sample results (GroupNorm statistics are per sample)."""
+    import brepgen_amd as bga
+    from oracle import vae as ov
+    sd = ov.seeded_state_dict(ov.edge_decoder_spec(), 77)
+    m = bga.AutoencoderKL1DFastDecode(**pc.EDGE_CFG)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.compute_dtype = F32
+    z = torch.randn(40, 3, 4, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        full = m(z)
+        m.IM2COL_BUDGET = 1 << 18                       # force several chunks
+        chunked = m(z)
+        one = m(z[17:18])
+    assert torch.equal(full, chunked) and float((full[17:18] - one).abs().max()) < 1e-5
