@@ -103,6 +103,7 @@ def main():
     torch.manual_seed(0)
     net = bga.SurfZNet(False).to(dev).eval()
     net.compute_dtype = torch.bfloat16
+    net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
     z, pos, mask = make_inputs(B_PER_GPU, dev, 1234 + rank)
     sch = bga.DDPMScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
                             beta_start=0.0001, beta_end=0.02, clip_sample=True, clip_sample_range=3)

@@ -25,7 +25,7 @@ constexpr int VS = 68;                     // V^T row stride (bf16 elements)
 constexpr int HEAD_LDS = 64 * 128 + 64 * VS * 2;   // K tile + V^T tile bytes per head slot = 16896
 
 template <int WPH>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const __bf16* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restrict__ qkv,
                                                         const uint8_t* __restrict__ key_pad,
                                                         __bf16* __restrict__ out, int B, int N) {
     constexpr int HPW = 4 / WPH;               // heads per workgroup

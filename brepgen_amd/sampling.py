@@ -147,7 +147,7 @@ class CascadeSampler:
 
     @torch.no_grad()
     def sample(self, batch_size, num_surfaces, num_edges, generator=None, device="cuda",
-               pndm_pos_steps=158, ddpm_pos_steps=250, stop_after=None):
+               pndm_pos_steps=158, ddpm_pos_steps=250, pndm_z_steps=None, stop_after=None):
         surfpos_net, surfz_net, edgepos_net, edgez_net = self.nets
         dev = torch.device(device)
         lo, hi = shard_range(batch_size, self.rank, self.world)
@@ -179,7 +179,7 @@ class CascadeSampler:
             surfZ = sharded_randn((batch_size, S, 48), generator, self.rank, self.world, dev)
             sp2, sm2 = (self._rep(surfPos, 2), self._rep(surfMask, 2)) if self.use_cf else (surfPos, surfMask)
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps:
+            for t in self.pndm.timesteps[:pndm_z_steps]:
                 td = t.reshape(-1).to(dev)
                 surfZ = self._step(self.pndm, lambda g: surfz_net(self._rep(surfZ, 2) if g else surfZ, td, sp2, sm2, cl),
                                    surfZ, t, td)
@@ -211,7 +211,7 @@ class CascadeSampler:
             edgeZV = sharded_randn((batch_size, S, E, 18), generator, self.rank, self.world, dev)
             ep2, em2 = (self._rep(edgePos, 2), self._rep(edgeM, 2)) if self.use_cf else (edgePos, edgeM)
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps:
+            for t in self.pndm.timesteps[:pndm_z_steps]:
                 td = t.reshape(-1).to(dev)
                 edgeZV = self._step(self.pndm, lambda g: edgez_net(self._rep(edgeZV, 2) if g else edgeZV, td, ep2, sp2,
                                                                     sz2, em2, cl), edgeZV, t, td)

@@ -1,0 +1,90 @@
+"""-m gpu: the whole denoising cascade (sample.py:120-286) on the HIP path vs the same cascade driven by the CPU
+oracle (oracle nets + restated schedulers + the same seeded CPU noise), fp32, shortened schedules."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, thr=0.08):
+    """Reference order of operations, CPU: sample.py:126-286 with the oracle in place of network.py/diffusers."""
+    from brepgen_amd.sampling import dedup_edges, dedup_surfaces
+    from brepgen_amd.utils import randn_tensor
+    from oracle import denoisers as orc
+    from oracle.schedulers import OracleDDPM, OraclePNDM
+    pndm, ddpm = OraclePNDM(), OracleDDPM(clip_sample=True, clip_sample_range=3)
+    cl = torch.tensor([class_id] * B + [0] * B).reshape(-1, 1) if use_cf else None
+    rep = (lambda t: t.repeat(2, *([1] * (t.dim() - 1)))) if use_cf else (lambda t: t)
+
+    def guided(e):
+        return e[:B] * (1 + w) - e[B:] * w if use_cf else e
+
+    x = randn_tensor((B, S, 6), generator=gen)
+    pndm.set_timesteps(200)
+    for t in pndm.timesteps[:n_pos]:
+        x = pndm.step(guided(orc.surfpos_forward(sds[0], rep(x), t.reshape(-1), cl)), t, x)
+    if not use_cf:
+        x = x.repeat(1, 2, 1)
+        S *= 2
+    ddpm.set_timesteps(1000)
+    for t in ddpm.timesteps[-n_ddpm:]:
+        z = randn_tensor((B, S, 6), generator=gen) if int(t) > 0 else None
+        x = ddpm.step(guided(orc.surfpos_forward(sds[0], rep(x), t.reshape(-1), cl)), t, x, noise=z)
+    surfPos, surfMask = dedup_surfaces(x, thr)
+    surfZ = randn_tensor((B, S, 48), generator=gen)
+    pndm.set_timesteps(200)
+    for t in pndm.timesteps[:n_z]:
+        surfZ = pndm.step(guided(orc.surfz_forward(sds[1], rep(surfZ), t.reshape(-1), rep(surfPos), rep(surfMask), cl)),
+                          t, surfZ)
+    edgePos = randn_tensor((B, S, E, 6), generator=gen)
+    pndm.set_timesteps(200)
+    for t in pndm.timesteps[:n_pos]:
+        e = orc.edgepos_forward(sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
+        edgePos = pndm.step(guided(e), t, edgePos)
+    ddpm.set_timesteps(1000)
+    for t in ddpm.timesteps[-n_ddpm:]:
+        z = randn_tensor((B, S, E, 6), generator=gen) if int(t) > 0 else None
+        e = orc.edgepos_forward(sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
+        edgePos = ddpm.step(guided(e), t, edgePos, noise=z)
+    edgeM = dedup_edges(edgePos, surfMask, thr)
+    edgeZV = randn_tensor((B, S, E, 18), generator=gen)
+    pndm.set_timesteps(200)
+    for t in pndm.timesteps[:n_z]:
+        e = orc.edgez_forward(sds[3], rep(edgeZV), t.reshape(-1), rep(edgePos), rep(surfPos), rep(surfZ), rep(edgeM), cl)
+        edgeZV = pndm.step(guided(e), t, edgeZV)
+    edgeZV = edgeZV.masked_fill(edgeM.unsqueeze(-1), 0.0)
+    return dict(surfPos=surfPos, surfMask=surfMask, surfZ=surfZ, edgePos=edgePos, edgeM=edgeM, edgeZV=edgeZV)
+
+
+@pytest.mark.parametrize("use_cf", [False, True])
+def test_cascade_matches_oracle_cascade(use_cf):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import brepgen_amd as bga
+    from brepgen_amd.sampling import CascadeSampler
+    from oracle import denoisers as orc
+    names = ["SurfPosNet", "SurfZNet", "EdgePosNet", "EdgeZNet"]
+    sds = [orc.seeded_state_dict(n, 50 + i, use_cf) for i, n in enumerate(names)]
+    nets = []
+    for n, sd in zip(names, sds):
+        m = getattr(bga, n)(use_cf)
+        m.load_state_dict(sd, strict=True)
+        nets.append(m.cuda().eval())
+    B, S, E = 2, 4, 3
+    n_pos, n_ddpm, n_z = 14, 6, 14          # 12 PRK + 2 PLMS evaluations, 6 ancestral steps (the last has t = 0)
+    kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001,
+              beta_end=0.02)
+    sampler = CascadeSampler(*nets, bga.PNDMScheduler(**kw), bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw),
+                             use_cf=use_cf, class_id=6, guidance=0.6, autocast=False)
+    with torch.no_grad():
+        got = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(11), pndm_pos_steps=n_pos,
+                             ddpm_pos_steps=n_ddpm, pndm_z_steps=n_z)
+        want = _oracle_cascade(sds, B, S, E, torch.Generator().manual_seed(11), use_cf, 6, 0.6, n_pos, n_ddpm, n_z)
+    assert set(got) == set(want)
+    for k in ("surfMask", "edgeM"):
+        assert torch.equal(got[k].cpu(), want[k]), k
+    for k in ("surfPos", "surfZ", "edgePos", "edgeZV"):
+        assert got[k].shape == want[k].shape, k
+        d = float((got[k].cpu() - want[k]).abs().max())
+        assert np.isfinite(d) and d < 5e-4, (k, d)     # fp32 path: per-step 1e-5 compounded over ~50 steps
