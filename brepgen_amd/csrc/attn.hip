@@ -24,10 +24,27 @@ constexpr int QKV_LD = 3 * BG_D_MODEL;     // 2304
 constexpr int VS = 68;                     // V^T row stride (bf16 elements)
 constexpr int HEAD_LDS = 64 * 128 + 64 * VS * 2;   // K tile + V^T tile bytes per head slot = 16896
 
-template <int WPH>
-__global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restrict__ qkv,
-                                                        const uint8_t* __restrict__ key_pad,
-                                                        __bf16* __restrict__ out, int B, int N) {
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <bool F16> struct AElem;
+template <> struct AElem<false> {
+    using T = __bf16; using V8 = bf16x8; using V4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct AElem<true> {
+    using T = _Float16; using V8 = f16x8; using V4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int WPH, bool F16>
+__global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
+                                                        void* __restrict__ out_, int B, int N) {
+    using E = AElem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    const T* __restrict__ qkv = reinterpret_cast<const T*>(qkv_);
+    T* __restrict__ out = reinterpret_cast<T*>(out_);
     constexpr int HPW = 4 / WPH;               // heads per workgroup
     constexpr int KPI = 8 / WPH;               // K-tile DMA instructions per wave
     __shared__ __attribute__((aligned(16))) unsigned char lds[HPW * HEAD_LDS + 256];
@@ -40,17 +57,17 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restr
     const int head = blockIdx.y * HPW + hl;
     const int q0 = (blockIdx.x * WPH + qt) * 32;
     unsigned char* ktile = lds + hl * HEAD_LDS;
-    __bf16* vt = reinterpret_cast<__bf16*>(ktile + 64 * 128);
-    const __bf16* base = qkv + (size_t)b * N * QKV_LD + head * 64;
+    T* vt = reinterpret_cast<T*>(ktile + 64 * 128);
+    const T* base = qkv + (size_t)b * N * QKV_LD + head * 64;
 
     // Q fragments (B operand of S^T = K Q^T): lane = (query l&31, k-chunk h) for each 16-wide slice of d
-    bf16x8 qf[4];
+    V8 qf[4];
     {
         int qrow = q0 + (lane & 31);
         qrow = qrow < N ? qrow : N - 1;
-        const __bf16* qp = base + (size_t)qrow * QKV_LD;
+        const T* qp = base + (size_t)qrow * QKV_LD;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + (ks * 2 + h) * 8);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + (ks * 2 + h) * 8);
     }
     // K fragment read offsets (A operand): key row l&31 (+32 for the second sub-tile)
     int k_off[2], k_sw[2];
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restr
             const int row = idx >> 3, dc = idx & 7;
             int key = kt * 64 + row;
             key = key < N ? key : N - 1;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (size_t)key * QKV_LD + 2 * BG_D_MODEL + dc * 8);
+            const V8 v = *reinterpret_cast<const V8*>(base + (size_t)key * QKV_LD + 2 * BG_D_MODEL + dc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) vt[(dc * 8 + e) * VS + row] = v[e];
         }
@@ -111,8 +128,8 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restr
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + k_off[sub] + (((ks * 2 + h) ^ k_sw[sub]) << 4));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                const V8 kf = *reinterpret_cast<const V8*>(ktile + k_off[sub] + (((ks * 2 + h) ^ k_sw[sub]) << 4));
+                s = E::mfma(kf, qf[ks], s);
             }
             // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
             float mloc = -INFINITY;
@@ -141,18 +158,18 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restr
             // ---- O^T += V^T P^T : two 16-key slices, two 32-row d tiles ----
 #pragma unroll
             for (int sl = 0; sl < 2; ++sl) {
-                bf16x8 pb;
+                V8 pb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pb[e] = (__bf16)s[8 * sl + e];
+                for (int e = 0; e < 8; ++e) pb[e] = (T)s[8 * sl + e];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const __bf16* vrow = vt + (dt * 32 + (lane & 31)) * VS + sub * 32 + 16 * sl + 4 * h;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
-                    bf16x8 va;
+                    const T* vrow = vt + (dt * 32 + (lane & 31)) * VS + sub * 32 + 16 * sl + 4 * h;
+                    const V4 lo = *reinterpret_cast<const V4*>(vrow);
+                    const V4 hi = *reinterpret_cast<const V4*>(vrow + 8);
+                    V8 va;
                     va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
                     va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb, o[dt], 0, 0, 0);
+                    o[dt] = E::mfma(va, pb, o[dt]);
                 }
             }
         }
@@ -162,14 +179,16 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(const __bf16* __restr
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + (lane & 31);
     if (q < N) {
-        __bf16* op = out + ((size_t)b * N + q) * BG_D_MODEL + head * 64;
+        T* op = out + ((size_t)b * N + q) * BG_D_MODEL + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = dt * 32 + 8 * g4 + 4 * h;
-                *reinterpret_cast<bf16x4*>(op + d) = to_bf16x4(o[dt][4 * g4 + 0] * inv, o[dt][4 * g4 + 1] * inv,
-                                                              o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                V4 pk;
+                pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
+                pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<V4*>(op + d) = pk;
             }
     }
 }
@@ -225,21 +244,26 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s) {
     if (B <= 0 || N <= 0) return 0;
-    const double es = dtype == BG_BF16 ? 2.0 : 4.0;
+    const double es = dtype == BG_F32 ? 4.0 : 2.0;
     // algorithmic: QK^T + PV over all heads, no mask discount; bytes: qkv read once, out written once
-    ProfScope prof(dtype == BG_BF16 ? PK_ATTN_BF16 : PK_ATTN_F32, 4.0 * B * BG_N_HEAD * (double)N * N * BG_D_HEAD,
+    ProfScope prof(dtype == BG_F32 ? PK_ATTN_F32 : PK_ATTN_BF16, 4.0 * B * BG_N_HEAD * (double)N * N * BG_D_HEAD,
                    es * B * (double)N * (QKV_LD + BG_D_MODEL), s);
-    if (dtype == BG_BF16) {
-        const __bf16* q = reinterpret_cast<const __bf16*>(qkv);
-        __bf16* o = reinterpret_cast<__bf16*>(out);
+    if (dtype == BG_BF16 || dtype == BG_F16) {
+        const bool f16 = dtype == BG_F16;
         if (N <= 32) {
-            hipLaunchKernelGGL(attn_bf16_kernel<1>, dim3(1, BG_N_HEAD / 4, B), dim3(256), 0, s, q, key_pad, o, B, N);
+            const dim3 grid(1, BG_N_HEAD / 4, B);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<1, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            else hipLaunchKernelGGL((attn16_kernel<1, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
         } else if (N <= 64) {
-            hipLaunchKernelGGL(attn_bf16_kernel<2>, dim3(1, BG_N_HEAD / 2, B), dim3(256), 0, s, q, key_pad, o, B, N);
+            const dim3 grid(1, BG_N_HEAD / 2, B);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<2, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            else hipLaunchKernelGGL((attn16_kernel<2, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
         } else {
-            hipLaunchKernelGGL(attn_bf16_kernel<4>, dim3((N + 127) / 128, BG_N_HEAD, B), dim3(256), 0, s, q, key_pad, o, B, N);
+            const dim3 grid((N + 127) / 128, BG_N_HEAD, B);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<4, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
         }
-        return launch_status("attn_bf16");
+        return launch_status("attn16");
     }
     if (dtype == BG_F32) {
         const size_t shm = (size_t)4 * N * sizeof(float);

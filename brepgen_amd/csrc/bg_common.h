@@ -40,6 +40,8 @@ extern int g_tune[TUNE_COUNT];
 // ---- vector types -----------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -62,6 +64,14 @@ __device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) 
     return r;
 }
 
+// 4 floats -> 4 packed 16-bit values of dtype `dt` (BG_BF16 | BG_F16), as a 64-bit payload
+__device__ __forceinline__ uint2 pack4_16(float a, float b, float c, float d, int dt) {
+    union { bf16x4 b; half4_t h; uint2 u; } r;
+    if (dt == BG_F16) { r.h[0] = (_Float16)a; r.h[1] = (_Float16)b; r.h[2] = (_Float16)c; r.h[3] = (_Float16)d; }
+    else r.b = to_bf16x4(a, b, c, d);
+    return r.u;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // XCD-aware bijective remap of a 1-D block id (MI355X: block b runs on XCD b % 8, each XCD has a private
@@ -81,13 +91,13 @@ struct GemmArgs {
     const float* bias;        // [N_pad] or null
     void* out; int ldc;
     int M, N, N_pad, K;
-    int out_dtype;            // BG_F32 | BG_BF16
+    int out_dtype;            // BG_F32, or the 16-bit operand dtype
     int act;                  // bg_act
     const float* add; int ld_add; int add_div;   // optional fp32 addend, row (m / add_div)
     const float* add2 = nullptr; int ld_add2 = 0; int add2_div = 1;   // optional second addend
 };
 int gemm_f32(const GemmArgs& g, hipStream_t s);
-int gemm_bf16(const GemmArgs& g, hipStream_t s);
+int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s);   // ab_dtype: BG_BF16 | BG_F16
 int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s);
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps,

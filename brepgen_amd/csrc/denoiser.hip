@@ -110,7 +110,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
                size_t ws_bytes, hipStream_t s) {
     const int net = w->net, B = in->B, S = in->S, E = (net >= BG_EDGEPOS) ? in->E : 1;
     BG_REQUIRE(net >= BG_SURFPOS && net <= BG_EDGEZ, BG_E_ARG, "bg_denoiser_fwd: bad net id %d", net);
-    BG_REQUIRE(w->dtype == BG_BF16 || w->dtype == BG_F32, BG_E_DTYPE, "bg_denoiser_fwd: compute dtype %d", w->dtype);
+    BG_REQUIRE(w->dtype == BG_BF16 || w->dtype == BG_F16 || w->dtype == BG_F32, BG_E_DTYPE, "bg_denoiser_fwd: compute dtype %d", w->dtype);
     BG_REQUIRE(B > 0 && S > 0 && E > 0, BG_E_SHAPE, "bg_denoiser_fwd: empty shape B=%d S=%d E=%d", B, S, E);
     BG_REQUIRE(in->n_timesteps == 1 || in->n_timesteps == B, BG_E_SHAPE, "bg_denoiser_fwd: n_timesteps must be 1 or B");
     BG_REQUIRE(in->x && in->timesteps && eps_out && workspace, BG_E_ARG, "bg_denoiser_fwd: null pointer");

@@ -11,7 +11,7 @@ namespace bg {
 // Each lane owns 3 float4 (columns lane*4 + 256*j): fully coalesced 1 KiB per wave-load.
 // Two-pass statistics in registers (mean, then centred variance) == torch.nn.LayerNorm numerics.
 // ------------------------------------------------------------------------------------------------
-template <bool OUT_BF16, bool SILU>
+template <int OUT, bool SILU>    // OUT: BG_F32 | BG_F16 | BG_BF16
 __global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, void* __restrict__ y, int M,
                                                     float eps) {
@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x,
         o.z = v[j].z * rstd * g.z + b.z;
         o.w = v[j].w * rstd * g.w + b.w;
         if (SILU) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
-        if (OUT_BF16) {
-            bf16x4* yr = reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y) + (size_t)row * 768);
-            yr[lane + 64 * j] = to_bf16x4(o.x, o.y, o.z, o.w);
+        if (OUT != BG_F32) {
+            uint2* yr = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + (size_t)row * 768);
+            yr[lane + 64 * j] = pack4_16(o.x, o.y, o.z, o.w, OUT);
         } else {
             float4* yr = reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (size_t)row * 768);
             yr[lane + 64 * j] = o;
@@ -58,13 +58,16 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
                  hipStream_t s) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
-    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_BF16 ? 2.0 : 4.0)), s);
+    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_F32 ? 4.0 : 2.0)), s);
     if (y_dtype == BG_BF16) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<true, true>), grid, block, 0, s, x, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<true, false>), grid, block, 0, s, x, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, g, b, y, M, eps);
+    } else if (y_dtype == BG_F16) {
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F16, true>), grid, block, 0, s, x, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F16, false>), grid, block, 0, s, x, g, b, y, M, eps);
     } else if (y_dtype == BG_F32) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<false, true>), grid, block, 0, s, x, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<false, false>), grid, block, 0, s, x, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F32, true>), grid, block, 0, s, x, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F32, false>), grid, block, 0, s, x, g, b, y, M, eps);
     } else {
         set_error("layernorm: unsupported output dtype %d", y_dtype);
         return BG_E_DTYPE;

@@ -1,0 +1,578 @@
+// 16-bit (bf16 / fp16) MFMA GEMM with fused epilogues -- the QKV / out-proj / FFN1 / FFN2 / embed / fc_out Linears
+// of the denoisers (network.py:1076-1099) and every convolution of the VAE decoders (as im2col GEMMs), i.e. >95 % of
+// the path's FLOPs.  MFMA-bound.
+//
+//   out[m,n] = act(sum_k a[m,k] * w[n,k] + bias[n]) (+ add[(m / add_div), n] (+ add2[...]))   a, w 16-bit; fp32 accumulate
+//
+// Design (gfx950):
+//   * tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), v_mfma_f32_32x32x16_{bf16,f16}: 16 fp32 accumulators per
+//     32x32 MFMA tile, 2 x 2 MFMA tiles per wave;
+//   * both operands are K-contiguous (activations [M,K], nn.Linear weights [N,K]) so A and B fragments share one
+//     16-byte-per-lane shape: lane l holds rows (l & 31), k-chunk (l >> 5) of each 16-wide k-slice;
+//   * L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction = 8 rows x 128 B) into a ring over K,
+//     counted vmcnt + raw s_barrier, ONE barrier per 64-wide K-step;
+//   * the LDS image is XOR-swizzled at 16-byte granularity, chunk' = chunk ^ ((row >> 1) & 7).  The DMA writes
+//     lane-linear, so the permutation is applied to the per-lane SOURCE address and again on the ds_read_b128 side
+//     (same involution): every 16-lane service group of ds_read_b128 touches 16 distinct 16-byte slots of the
+//     256-byte bank row -- measured SQ_LDS_BANK_CONFLICT = 0;
+//   * fragment reads are software-pipelined one k-slice ahead of the MFMAs (order pinned with sched_barrier);
+//   * shipped kernel = the PERSISTENT one (gemm16_persistent_kernel): 2 workgroups per CU stay resident and walk
+//     the tile list, the DMA stream runs across tile seams, the epilogue works out of a small wave-private LDS patch
+//     that does not alias the ring, bias / ReLU / fp32-residual / broadcast adds fused, full-line global stores;
+//   * XCD-aware tile order: workgroups that run concurrently on one XCD take consecutive tiles (shared A row panel).
+// The exploration behind this shape (3-stage rings, 256-row tiles, register epilogue, loader/consumer wave
+// specialisation, ablations) is summarised in DESIGN.md section 4 with the logs under profiles/r01/; those kernel
+// variants live in the git history (commit "Persistent 128x128 GEMM ...").
+#include "bg_common.h"
+#include <type_traits>
+
+namespace bg {
+
+constexpr int G_BK = 64;            // 16-bit elements per K-step = 128 bytes per tile row
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+template <bool F16> struct Elem;
+template <> struct Elem<false> {
+    using T = __bf16; using V8 = bf16x8; using V4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ V4 pack4(float a, float b, float c, float d) { return to_bf16x4(a, b, c, d); }
+};
+template <> struct Elem<true> {
+    using T = _Float16; using V8 = f16x8; using V4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ V4 pack4(float a, float b, float c, float d) {
+        V4 r; r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d; return r;
+    }
+};
+
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
+    // dst = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// BM x BN block tile, WM x WN waves (each wave (BM/WM) x (BN/WN)), STAGES-deep LDS ring over K.
+template <bool F16, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
+    using E = Elem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;           // 32x32 MFMA tiles per wave
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int LDS_BYTES = (STAGES * STAGE_BYTES > EPI_BYTES) ? STAGES * STAGE_BYTES : EPI_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces must divide evenly over the waves");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(g.a);
+    const T* __restrict__ W = reinterpret_cast<const T*>(g.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt_n = g.N_pad / BN;
+    const int nblk = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nblk);
+    const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
+
+    // ---- LDS-DMA source addresses (per lane), destination bases (per wave) ----
+    constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;   // wave-instructions per wave per stage
+    constexpr int PER_STAGE = A_INSTR + B_INSTR;
+    const T* a_src[A_INSTR];
+    const T* b_src[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int grow = m0 + row;
+        grow = grow < g.M ? grow : g.M - 1;                       // clamp: rows >= M are never stored
+        a_src[j] = A + (size_t)grow * g.lda + c * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+        const int row = (wave * B_INSTR + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        b_src[j] = W + (size_t)(n0 + row) * g.K + c * 8;
+    }
+    // one 1-KiB DMA piece (p < A_INSTR: activation rows, else weight rows) of K-step k0 into ring slot `stage`
+    auto issue_piece = [&](int p, int stage, int k0) {
+        unsigned char* sa = lds + stage * STAGE_BYTES;
+        if (p < A_INSTR) lds_dma16(a_src[p] + k0, sa + (wave * A_INSTR + p) * 1024);
+        else lds_dma16(b_src[p - A_INSTR] + k0, sa + BM * 128 + (wave * B_INSTR + (p - A_INSTR)) * 1024);
+    };
+    auto issue = [&](int stage, int k0) {
+#pragma unroll
+        for (int p = 0; p < PER_STAGE; ++p) issue_piece(p, stage, k0);
+    };
+
+    // ---- fragment read offsets ----
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + (lane & 31);
+        a_off[i] = row * 128;
+        a_sw[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * (TN * 32) + i * 32 + (lane & 31);
+        b_off[i] = BM * 128 + row * 128;
+        b_sw[i] = (row >> 1) & 7;
+    }
+    const int h = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- K loop: STAGES-1 tiles of LDS-DMA in flight, ONE barrier per 64-wide K-step.  Counted vmcnt + raw
+    // s_barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) at every step. ----
+    const int KT = g.K / G_BK;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < KT) issue(s, s * G_BK);
+    int stage = 0;                                                // kt % STAGES
+    auto ktile = [&](int kt, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
+        // tile kt must have landed; up to min(STAGES-2, KT-1-kt) younger tiles may stay in flight
+        const int younger = (KT - 1 - kt) < (STAGES - 2) ? (KT - 1 - kt) : (STAGES - 2);
+        if (younger >= 2) wait_vmcnt<2 * PER_STAGE>();
+        else if (younger == 1) wait_vmcnt<PER_STAGE>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my fragment reads of tile kt-1 are complete
+        __builtin_amdgcn_s_barrier();                             // everybody's DMA of tile kt landed; ring slot
+                                                                  // (kt-1) % STAGES is free for tile kt+STAGES-1
+        // The DMA pieces of tile kt+STAGES-1 are issued one at a time BETWEEN the MFMAs of this K-step: an LDS-DMA
+        // instruction costs ~60-180 issue cycles, and both waves of a SIMD leave the barrier together, so issuing
+        // all pieces up front would idle the matrix pipe for that long every K-step.
+        int ns = stage + STAGES - 1;
+        ns = ns >= STAGES ? ns - STAGES : ns;
+        const int k0n = (kt + STAGES - 1) * G_BK;
+        const unsigned char* st = lds + stage * STAGE_BYTES;
+        V8 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int ks, int buf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[buf][i] = *reinterpret_cast<const V8*>(st + a_off[i] + (((ks * 2 + h) ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[buf][j] = *reinterpret_cast<const V8*>(st + b_off[j] + (((ks * 2 + h) ^ b_sw[j]) << 4));
+        };
+        constexpr int NMFMA = 4 * TM * TN;
+        load_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) load_frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = E::mfma(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
+                    {   // DMA pieces [lo, hi) are scheduled right after MFMA number idx of NMFMA (compile-time)
+                        const int idx = (ks * TM + i) * TN + j;
+                        const int lo = idx * PER_STAGE / NMFMA, hi = (idx + 1) * PER_STAGE / NMFMA;
+                        if (hi > lo) {
+                            if (more) {
+#pragma unroll
+                                for (int p = lo; p < hi; ++p) issue_piece(p, ns, k0n);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+    };
+    // steady state issues the DMA pieces of tile kt+STAGES-1; the last STAGES-1 K-steps have nothing left to fetch
+    int kt = 0;
+    for (; kt + STAGES - 1 < KT; ++kt) ktile(kt, std::true_type{});
+    for (; kt < KT; ++kt) ktile(kt, std::false_type{});
+    __syncthreads();                                              // all fragment reads done: LDS is free
+
+    // ---- epilogue: accumulators -> wave-private LDS patch -> coalesced rows ----
+    constexpr int PW = TN * 32;                                   // patch width (floats)
+    float* patch = reinterpret_cast<float*>(lds) + wave * (TM * 32 * PW);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D layout of the 32x32 MFMA
+                patch[pr * PW + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    __syncthreads();
+
+    constexpr int LPR = PW / 4;                                   // lanes per patch row (float4 each)
+    constexpr int RPI = 64 / LPR;                                 // rows per iteration
+    const int rr = lane / LPR, c4 = (lane % LPR) * 4;
+    const int gcol = n0 + wn * PW + c4;
+    const bool vec = (g.N == g.N_pad) && ((g.ldc & 3) == 0) && (g.add == nullptr || (g.ld_add & 3) == 0) &&
+                     (g.add2 == nullptr || (g.ld_add2 & 3) == 0);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bias = *reinterpret_cast<const float4*>(g.bias + gcol);
+#pragma unroll 4
+    for (int it = 0; it < TM * 32 / RPI; ++it) {
+        const int pr = it * RPI + rr;
+        const int grow = m0 + wm * (TM * 32) + pr;
+        if (grow >= g.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(&patch[pr * PW + c4]);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (g.act == BG_ACT_RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (vec) {
+            if (g.add) {
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add + (size_t)(grow / g.add_div) * g.ld_add + gcol);
+                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+            }
+            if (g.add2) {
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(grow / g.add2_div) * g.ld_add2 + gcol);
+                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+            }
+            if (g.out_dtype != BG_F32)
+                *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
+                    E::pack4(v.x, v.y, v.z, v.w);
+            else
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
+        } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = gcol + e;
+                if (col >= g.N) continue;
+                float o = vv[e];
+                if (g.add) o += g.add[(size_t)(grow / g.add_div) * g.ld_add + col];
+                if (g.add2) o += g.add2[(size_t)(grow / g.add2_div) * g.ld_add2 + col];
+                if (g.out_dtype != BG_F32) reinterpret_cast<T*>(g.out)[(size_t)grow * g.ldc + col] = (T)o;
+                else reinterpret_cast<float*>(g.out)[(size_t)grow * g.ldc + col] = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Persistent kernel ("P"): the shipped configuration for N % 128 == 0.
+//
+// Measured (profiles/r01/gemm_ablation.log, gemm_lc_abl2.log): at K = 768 a 128x128 tile spends ~12 x 1 us in
+// its K loop and another ~5 us in epilogue + wave drain + workgroup launch + first-DMA latency of its successor.
+// Here 2 workgroups per CU stay resident and walk the tile list; the LDS-DMA stream never stops at a tile
+// boundary (the first K-step of the NEXT tile is issued during the last K-step of the current one), the epilogue
+// runs out of a small wave-private LDS patch that does not alias the ring, and nothing is re-launched.
+//   LDS: ring 2 x 32 KiB + 4 x 4 KiB patches = 80 KiB  ->  2 workgroups per CU.
+//   16-bit output: neighbouring lanes swap one accumulator so each lane owns a bf16 pair, the patch holds a
+//   32 x 64 bf16 slab (128-byte rows) -> 16-byte-per-lane, full-line global stores.
+//   fp32 output / residual: 32 x 32 fp32 slab per MFMA tile -> 128-byte row segments, residual added in flight.
+// ------------------------------------------------------------------------------------------------------
+template <bool F16, bool INSTR>
+__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int n_tiles, unsigned long long* dbg) {
+    using E = Elem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;                  // 32 KiB
+    constexpr int RING = 2 * STAGE_BYTES;
+    constexpr int A_INSTR = 4, B_INSTR = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[RING + 4 * 4096];
+
+    const T* __restrict__ A = reinterpret_cast<const T*>(g.a);
+    const T* __restrict__ W = reinterpret_cast<const T*>(g.w);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+    const int nt_n = g.N_pad / BN;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);                   // tiles first, first+G, ... : co-running workgroups
+    if (first >= n_tiles) return;                                 // of one XCD take consecutive tiles (shared A panel)
+
+    // per-lane DMA source rows / swizzled chunks (tile independent part)
+    int a_row[A_INSTR], a_chunk[A_INSTR], b_row[B_INSTR], b_chunk[B_INSTR];
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+        a_row[j] = (wave * A_INSTR + j) * 8 + (lane >> 3);
+        a_chunk[j] = ((lane & 7) ^ ((a_row[j] >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+        b_row[j] = (wave * B_INSTR + j) * 8 + (lane >> 3);
+        b_chunk[j] = ((lane & 7) ^ ((b_row[j] >> 1) & 7)) * 8;
+    }
+    const T* a_src[A_INSTR];
+    const T* b_src[B_INSTR];
+    auto set_tile = [&](int L, int& m0, int& n0) {
+        m0 = (L / nt_n) * BM;
+        n0 = (L % nt_n) * BN;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) {
+            int grow = m0 + a_row[j];
+            grow = grow < g.M ? grow : g.M - 1;
+            a_src[j] = A + (size_t)grow * g.lda + a_chunk[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) b_src[j] = W + (size_t)(n0 + b_row[j]) * g.K + b_chunk[j];
+    };
+    auto issue = [&](int slot, int k0) {
+        unsigned char* sa = lds + slot * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) lds_dma16(a_src[j] + k0, sa + (wave * A_INSTR + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < B_INSTR; ++j) lds_dma16(b_src[j] + k0, sa + BM * 128 + (wave * B_INSTR + j) * 1024);
+    };
+
+    int a_off[TM], a_sw[TM], b_off[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * 64 + i * 32 + (lane & 31);
+        a_off[i] = row * 128;
+        a_sw[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int row = wn * 64 + i * 32 + (lane & 31);
+        b_off[i] = BM * 128 + row * 128;
+        b_sw[i] = (row >> 1) & 7;
+    }
+
+    unsigned* patch = reinterpret_cast<unsigned*>(lds + RING + wave * 4096);
+    const bool half_fast = g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr;
+    const int KT = g.K / G_BK;
+
+    int m0, n0;
+    unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0;
+    if (INSTR) t_begin = __builtin_amdgcn_s_memtime();
+    set_tile(first, m0, n0);
+    issue(0, 0);
+    int slot = 0;
+    for (int L = first; L < n_tiles; L += G) {
+        const bool has_next = L + G < n_tiles;
+        const int cm0 = m0, cn0 = n0;                             // coordinates of the tile being computed
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < KT; ++kt) {
+            unsigned long long ta = 0;
+            if (INSTR) ta = __builtin_amdgcn_s_memtime();
+            wait_vmcnt<0>();                                      // my pieces of this K-step (and older stores) done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            unsigned long long tb = 0;
+            if (INSTR) { tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; }
+            if (kt + 1 < KT) {
+                issue(slot ^ 1, (kt + 1) * G_BK);
+            } else if (has_next) {                                // keep the DMA stream running across the tile seam
+                set_tile(L + G, m0, n0);
+                issue(slot ^ 1, 0);
+            }
+            const unsigned char* st = lds + slot * STAGE_BYTES;
+            V8 af[2][TM], bf[2][TN];
+            auto load_frags = [&](int ks, int buf) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[buf][i] = *reinterpret_cast<const V8*>(st + a_off[i] + (((ks * 2 + h) ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[buf][j] = *reinterpret_cast<const V8*>(st + b_off[j] + (((ks * 2 + h) ^ b_sw[j]) << 4));
+            };
+            load_frags(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) load_frags(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = E::mfma(af[ks & 1][i], bf[ks & 1][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot ^= 1;
+            if (INSTR) {
+                asm volatile("s_nop 0" ::: "memory");
+                t_comp += __builtin_amdgcn_s_memtime() - tb;
+            }
+        }
+        unsigned long long te = 0;
+        if (INSTR) te = __builtin_amdgcn_s_memtime();
+
+        // ---------------- epilogue (wave-private patch; the ring already receives the next tile) ----------------
+        const int rbase = cm0 + wm * 64, cbase = cn0 + wn * 64;
+        float bias_l[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bias_l[j] = g.bias ? g.bias[cbase + j * 32 + (lane & 31)] : 0.f;
+        if (half_fast) {
+            T* out = reinterpret_cast<T*>(g.out);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp) {
+                        float a = acc[i][j][2 * rp] + bias_l[j], b = acc[i][j][2 * rp + 1] + bias_l[j];
+                        if (g.act == BG_ACT_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                        // even lane keeps row r (cols c, c+1), odd lane row r+1 (cols c-1, c)
+                        const float send = (lane & 1) ? a : b;
+                        // neighbour exchange inside lane pairs: DPP quad_perm [1,0,3,2] (pure VALU, no LDS crossbar)
+                        const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+                        const float lo = (lane & 1) ? recv : a, hi = (lane & 1) ? b : recv;
+                        const int r = 2 * rp + (lane & 1);
+                        const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                        union { T v[2]; unsigned u; } pk;
+                        pk.v[0] = (T)lo; pk.v[1] = (T)hi;
+                        patch[prow * 32 + j * 16 + ((lane & 31) >> 1)] = pk.u;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int prow = it * 8 + (lane >> 3), chunk = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&patch[prow * 32 + chunk * 4]);
+                    const int grow = rbase + i * 32 + prow;
+                    if (grow < g.M)
+                        *reinterpret_cast<uint4*>(out + (size_t)grow * g.ldc + cbase + chunk * 8) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            float* pf = reinterpret_cast<float*>(patch);
+            // residual / broadcast addend: all 16 row-segment loads of this wave go out FIRST (64 VGPRs), so their
+            // HBM/MALL latency overlaps the patch traffic instead of forming 16 serial round trips
+            float4 res[2][4];                                     // two MFMA tiles of residual rows in flight
+            auto load_res = [&](int t, int buf) {
+                const int i = t >> 1, j = t & 1;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int grow = rbase + i * 32 + it * 8 + (lane >> 3);
+                    grow = grow < g.M ? grow : g.M - 1;
+                    res[buf][it] = *reinterpret_cast<const float4*>(
+                        g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
+                }
+            };
+            if (g.add) { load_res(0, 0); load_res(1, 1); }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r] + bias_l[j];
+                        if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+                        pf[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + (lane & 31)] = v;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int prow = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                        float4 v = *reinterpret_cast<const float4*>(&pf[prow * 32 + c4]);
+                        const int grow = rbase + i * 32 + prow, gcol = cbase + j * 32 + c4;
+                        if (g.add) {
+                            const float4 a4 = res[(i * TN + j) & 1][it];
+                            v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                        }
+                        if (grow < g.M) {
+                            if (g.add2) {
+                                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(grow / g.add2_div) * g.ld_add2 + gcol);
+                                v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+                            }
+                            if (g.out_dtype != BG_F32)
+                                *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
+                                    E::pack4(v.x, v.y, v.z, v.w);
+                            else
+                                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
+                        }
+                    }
+                    if (g.add && i * TN + j + 2 < TM * TN) load_res(i * TN + j + 2, (i * TN + j) & 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+        }
+        if (INSTR) { t_epi += __builtin_amdgcn_s_memtime() - te; ++n_done; }
+    }
+    if (INSTR && dbg != nullptr && lane == 0) {
+        unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = t_wait; o[1] = t_comp; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime() - t_begin; o[4] = n_done;
+        o[5] = t_begin;
+    }
+}
+
+
+template <bool F16>
+static int launch16(const GemmArgs& g, hipStream_t s) {
+    const int m128 = (g.M + 127) / 128, m256 = (g.M + 255) / 256, n128 = g.N_pad / 128;
+    if (g.N_pad % 128 != 0) {                                     // narrow outputs (fc_out.3: 6/18/48 -> padded 64; conv_out 3)
+        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 64, 4, 1, 2>), dim3(m128 * (g.N_pad / 64)), dim3(256), 0, s, g);
+        return launch_status("gemm16");
+    }
+    const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
+                               (g.add2 == nullptr || g.ld_add2 % 4 == 0);
+    const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
+    if (variant == 10 || !persistent_ok) {                        // non-persistent 128x128, 2-stage ring
+        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
+    } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
+        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g);
+    } else {
+        const int nt = m128 * n128;
+        const int grid = nt < 512 ? nt : 512;                     // 2 resident workgroups per CU x 256 CUs
+        if (variant == 31) {                                      // s_memtime phase accounting (tools/gemm_instr.py)
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
+                ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, nt, dbg);
+        } else {
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, nt,
+                               (unsigned long long*)nullptr);
+        }
+    }
+    return launch_status("gemm16");
+}
+
+int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s) {
+    if (g.M <= 0) return 0;
+    if (g.K % G_BK != 0 || g.N_pad % 64 != 0 || g.lda % 8 != 0) {
+        set_error("gemm_16bit: need K %% 64 == 0, N_pad %% 64 == 0, lda %% 8 == 0 (K=%d N_pad=%d lda=%d)", g.K, g.N_pad, g.lda);
+        return BG_E_SHAPE;
+    }
+    if ((reinterpret_cast<uintptr_t>(g.a) & 15) || (reinterpret_cast<uintptr_t>(g.w) & 15) ||
+        (reinterpret_cast<uintptr_t>(g.out) & 15)) {
+        set_error("gemm_16bit: a / w / out must be 16-byte aligned");
+        return BG_E_ALIGN;
+    }
+    if (g.out_dtype != BG_F32 && g.out_dtype != ab_dtype) {
+        set_error("gemm_16bit: a 16-bit output must have the operand dtype (out %d, operands %d)", g.out_dtype, ab_dtype);
+        return BG_E_DTYPE;
+    }
+    // algorithmic cost: 2*M*N*K flops; bytes = operands once + output once (+ addends)
+    const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
+    const double bytes = 2.0 * g.M * g.K + 2.0 * g.N * (double)g.K + osz * g.M * g.N +
+                         (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0) + (g.add2 ? 4.0 * (g.M / g.add2_div) * g.N : 0.0);
+    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, 2.0 * g.M * g.N * (double)g.K, bytes, s);
+    return ab_dtype == BG_F16 ? launch16<true>(g, s) : launch16<false>(g, s);
+}
+
+}  // namespace bg

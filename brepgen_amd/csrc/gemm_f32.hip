@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (g.add) v += g.add[(size_t)(row / g.add_div) * g.ld_add + col];
         if (g.add2) v += g.add2[(size_t)(row / g.add2_div) * g.ld_add2 + col];
         if (g.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(g.out)[(size_t)row * g.ldc + col] = (__bf16)v;
+        else if (g.out_dtype == BG_F16) reinterpret_cast<_Float16*>(g.out)[(size_t)row * g.ldc + col] = (_Float16)v;
         else reinterpret_cast<float*>(g.out)[(size_t)row * g.ldc + col] = v;
     }
 }
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return 0;
     const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
-    const double osz = g.out_dtype == BG_BF16 ? 2.0 : 4.0;
+    const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
     ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K,
                    4.0 * g.M * g.K + 4.0 * g.N * (double)g.K + osz * g.M * g.N + (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0), s);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(nblk), dim3(256), 0, s, g);
@@ -83,7 +84,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
 
 int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s) {
     if (ab_dtype == BG_F32) return gemm_f32(g, s);
-    if (ab_dtype == BG_BF16) return gemm_bf16(g, s);
+    if (ab_dtype == BG_BF16 || ab_dtype == BG_F16) return gemm_16bit(g, ab_dtype, s);
     set_error("gemm: unsupported operand dtype %d", ab_dtype);
     return BG_E_DTYPE;
 }
@@ -96,7 +97,7 @@ extern "C" int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const
     BG_REQUIRE(a && w && out, BG_E_ARG, "bg_gemm_bias_act_fwd: null pointer");
     BG_REQUIRE(M >= 0 && N > 0 && K > 0 && N_pad >= N && lda >= K && ldc >= N, BG_E_SHAPE,
                "bg_gemm_bias_act_fwd: bad shape M=%d N=%d N_pad=%d K=%d lda=%d ldc=%d", M, N, N_pad, K, lda, ldc);
-    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_gemm_bias_act_fwd: out dtype %d", out_dtype);
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_gemm_bias_act_fwd: out dtype %d", out_dtype);
     BG_REQUIRE(add == nullptr || add_div >= 1, BG_E_ARG, "bg_gemm_bias_act_fwd: add_div must be >= 1");
     bg::GemmArgs g{a, lda, w, bias, out, ldc, M, N, N_pad, K, out_dtype, act, add, ld_add, add ? add_div : 1};
     return bg::gemm(g, ab_dtype, (hipStream_t)stream);

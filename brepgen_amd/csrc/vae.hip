@@ -51,7 +51,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 struct Im2colArgs {
-    const float* x; void* out; int out_bf16;
+    const float* x; void* out; int out_dtype;
     int S, Hin, Win, C, kh, kw, up;
     const float* stats; const float* gamma; const float* beta; int G; int act;
     const float* add;        // optional residual, added after norm + activation (1x1 / fp32-out use only)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
             const float4 ad = *reinterpret_cast<const float4*>(a.add + o);
             v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
         }
-        if (a.out_bf16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + o) = to_bf16x4(v.x, v.y, v.z, v.w);
+        if (a.out_dtype != BG_F32) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.out) + o) = pack4_16(v.x, v.y, v.z, v.w, a.out_dtype);
         else *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = v;
     }
 }
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void im2col_scalar_kernel(Im2colArgs a) {
         float v = 0.f;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)
             v = act_apply(a.x[(((size_t)s * a.Hin + (iy >> a.up)) * a.Win + (ix >> a.up)) * a.C + c], a.act);
-        if (a.out_bf16) reinterpret_cast<__bf16*>(a.out)[i] = (__bf16)v;
+        if (a.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(a.out)[i] = (__bf16)v;
+        else if (a.out_dtype == BG_F16) reinterpret_cast<_Float16*>(a.out)[i] = (_Float16)v;
         else reinterpret_cast<float*>(a.out)[i] = v;
     }
 }
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void upsample1d_cubic_kernel(const float* __re
 // ---- tiny self-attention of the VAE mid blocks: T tokens (16 for the 4x4 surface latent, 4 for the edge latent),
 // nh heads; one workgroup per sample; fp32 math.  qkv: [S*T, ld] with q | k | v at column offsets 0, C, 2C. ----
 __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict__ qkv, int ld, void* __restrict__ out,
-                                                         int out_bf16, int T, int C, int nh, float scale) {
+                                                         int out_dtype, int T, int C, int nh, float scale) {
     extern __shared__ float sc[];                           // [nh][T][T]
     const int s = blockIdx.x, d = C / nh, n_sc = nh * T * T;
     const float* base = qkv + (size_t)s * T * ld;
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict
         float acc = 0.f;
         for (int j = 0; j < T; ++j) acc = fmaf(p[j], base[(size_t)j * ld + 2 * C + col], acc);
         const size_t o = ((size_t)s * T + i) * C + col;
-        if (out_bf16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)acc;
+        if (out_dtype == BG_BF16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)acc;
+        else if (out_dtype == BG_F16) reinterpret_cast<_Float16*>(out)[o] = (_Float16)acc;
         else reinterpret_cast<float*>(out)[o] = acc;
     }
 }
@@ -206,13 +208,13 @@ extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hi
     BG_REQUIRE(x && out, BG_E_ARG, "bg_im2col: null pointer");
     BG_REQUIRE(S > 0 && Hin > 0 && Win > 0 && C > 0 && (kh & 1) && (kw & 1) && (up == 0 || up == 1), BG_E_SHAPE,
                "bg_im2col: bad shape");
-    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_im2col: out dtype %d", out_dtype);
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_im2col: out dtype %d", out_dtype);
     BG_REQUIRE(stats == nullptr || (gamma && beta && G > 0 && C % G == 0 && (C / G) % 4 == 0), BG_E_ARG,
                "bg_im2col: normalisation needs gamma, beta and (C/G) %% 4 == 0");
     BG_REQUIRE(add == nullptr || (kh == 1 && kw == 1 && C % 4 == 0), BG_E_ARG, "bg_im2col: residual add needs a 1x1 window");
-    bg::Im2colArgs a{x, out, out_dtype == BG_BF16, S, Hin, Win, C, kh, kw, up, stats, gamma, beta, G, act, add};
+    bg::Im2colArgs a{x, out, out_dtype, S, Hin, Win, C, kh, kw, up, stats, gamma, beta, G, act, add};
     const size_t rows = (size_t)S * (Hin << up) * (Win << up);
-    bg::ProfScope prof(bg::PK_MISC, 0.0, rows * (double)kh * kw * C * (4.0 + (out_dtype == BG_BF16 ? 2.0 : 4.0)),
+    bg::ProfScope prof(bg::PK_MISC, 0.0, rows * (double)kh * kw * C * (4.0 + (out_dtype == BG_F32 ? 4.0 : 2.0)),
                        (hipStream_t)stream);
     if (C % 4 == 0) {
         hipLaunchKernelGGL(bg::im2col_kernel, dim3(bg::cap_grid(rows * kh * kw * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
@@ -235,9 +237,9 @@ extern "C" int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype,
                              bg_stream_t stream) {
     BG_REQUIRE(qkv && out && S > 0 && T > 0 && nh > 0 && C % nh == 0 && ld >= 3 * C, BG_E_ARG, "bg_small_attn: bad arguments");
     BG_REQUIRE(nh * T * T <= 8192, BG_E_SHAPE, "bg_small_attn: nh*T*T = %d exceeds the LDS score buffer", nh * T * T);
-    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16, BG_E_DTYPE, "bg_small_attn: out dtype %d", out_dtype);
+    BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_small_attn: out dtype %d", out_dtype);
     bg::ProfScope prof(bg::PK_MISC, 4.0 * S * (double)T * T * C, 16.0 * S * (double)T * C, (hipStream_t)stream);
     hipLaunchKernelGGL(bg::small_attn_kernel, dim3(S), dim3(256), (size_t)nh * T * T * sizeof(float), (hipStream_t)stream, qkv, ld,
-                       out, out_dtype == BG_BF16, T, C, nh, scale);
+                       out, out_dtype, T, C, nh, scale);
     return bg::launch_status("small_attn");
 }

@@ -16,8 +16,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import (BG_BF16, BG_EDGEPOS, BG_EDGEZ, BG_F32, BG_SURFPOS, BG_SURFZ, DenoiserInputs, DenoiserWeights,
-                   check, ptr, stream)
+from ._lib import (BG_BF16, BG_EDGEPOS, BG_EDGEZ, BG_F16, BG_F32, BG_SURFPOS, BG_SURFZ, DenoiserInputs,
+                   DenoiserWeights, check, ptr, stream)
 
 D, H, DFF, NLAYER = 768, 12, 1024, 12
 
@@ -97,7 +97,7 @@ class _HipDenoiser(nn.Module):
         if dt in self._packs:
             return self._packs[dt]
         keep = []                                        # owns every packed tensor the descriptor points to
-        code = BG_BF16 if dt == torch.bfloat16 else BG_F32
+        code = {torch.bfloat16: BG_BF16, torch.float16: BG_F16, torch.float32: BG_F32}[dt]
 
         def f32(p):
             t = p.detach().to(torch.float32).contiguous()
@@ -115,7 +115,7 @@ class _HipDenoiser(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        pad = 64 if dt == torch.bfloat16 else 1
+        pad = 1 if dt == torch.float32 else 64
 
         def mlp(seq, w0_compute=False):
             m = _lib.MlpWeights()
@@ -158,7 +158,10 @@ class _HipDenoiser(nn.Module):
     def _dtype(self):
         if self.compute_dtype is not None:
             return self.compute_dtype
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if torch.is_autocast_enabled():                # follow the autocast dtype (the reference runs fp16, sample.py:121)
+            dt = torch.get_autocast_dtype('cuda')
+            return dt if dt in (torch.bfloat16, torch.float16) else torch.bfloat16
+        return torch.float32
 
     def _ws(self, nbytes, device):
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:

@@ -6,16 +6,16 @@ and returns torch tensors that own the output memory.  No torch math here -- onl
 import torch
 
 from . import _lib
-from ._lib import BG_ACT_NONE, BG_ACT_RELU, BG_BF16, BG_F32, check, ptr, stream  # noqa: F401
+from ._lib import BG_ACT_NONE, BG_ACT_RELU, BG_BF16, BG_F16, BG_F32, check, ptr, stream  # noqa: F401
 
-_DT = {torch.float32: BG_F32, torch.bfloat16: BG_BF16}
+_DT = {torch.float32: BG_F32, torch.bfloat16: BG_BF16, torch.float16: BG_F16}
 
 
 def bg_dtype(dt):
     try:
         return _DT[dt]
     except KeyError:
-        raise TypeError(f"brepgen_amd supports float32 and bfloat16 compute, not {dt}") from None
+        raise TypeError(f"brepgen_amd supports float32, bfloat16 and float16 compute, not {dt}") from None
 
 
 def _need_cuda(*ts):

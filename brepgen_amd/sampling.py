@@ -153,7 +153,13 @@ class CascadeSampler:
         lo, hi = shard_range(batch_size, self.rank, self.world)
         b = hi - lo
         cl = self._labels(b, dev)
-        ctx = torch.autocast("cuda", dtype=torch.bfloat16) if self.autocast else torch.autocast("cuda", enabled=False)
+        # autocast=True -> bf16 operands; a torch dtype (torch.float16: the reference's own autocast dtype) selects it
+        if self.autocast is True:
+            ctx = torch.autocast("cuda", dtype=torch.bfloat16)
+        elif self.autocast:
+            ctx = torch.autocast("cuda", dtype=self.autocast)
+        else:
+            ctx = torch.autocast("cuda", enabled=False)
         with ctx:
             # ---- 1-1 surface positions ----
             S = num_surfaces

@@ -16,7 +16,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._lib import BG_BF16, BG_F32, check, ptr, stream
+from ._lib import BG_BF16, BG_F16, BG_F32, check, ptr, stream
+
+_CODE = {torch.bfloat16: BG_BF16, torch.float16: BG_F16, torch.float32: BG_F32}
 
 CUBIC2 = [2 * v for v in (-0.01171875, -0.03515625, 0.11328125, 0.43359375, 0.43359375, 0.11328125, -0.03515625,
                           -0.01171875)]
@@ -164,7 +166,10 @@ class _HipVAE(nn.Module):
     def _dtype(self):
         if self.compute_dtype is not None:
             return self.compute_dtype
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype('cuda')
+            return dt if dt in (torch.bfloat16, torch.float16) else torch.bfloat16
+        return torch.float32
 
     # ---- packing ----
     @staticmethod
@@ -173,7 +178,7 @@ class _HipVAE(nn.Module):
         p = _Packed()
         use = dt if (dt == torch.float32 or k % 64 == 0) else torch.float32
         w = weight2d.detach().to(torch.float32)
-        pad = 64 if use == torch.bfloat16 else 1
+        pad = 1 if use == torch.float32 else 64
         if n % pad:
             w = torch.cat([w, w.new_zeros((-n) % pad, k)])
         p.w = w.to(use).contiguous()
@@ -207,7 +212,7 @@ class _HipVAE(nn.Module):
         st = self._stats(x, S, H * W, C, norm) if norm is not None else None
         g = norm.weight.detach().float().contiguous() if norm is not None else None
         b = norm.bias.detach().float().contiguous() if norm is not None else None
-        check(lib.bg_im2col(ptr(x), ptr(a), BG_BF16 if pk.dtype == torch.bfloat16 else BG_F32, S, H, W, C, kh, kw, up,
+        check(lib.bg_im2col(ptr(x), ptr(a), _CODE[pk.dtype], S, H, W, C, kh, kw, up,
                             ptr(st), ptr(g), ptr(b), norm.num_groups if norm is not None else 1, act, None, stream()),
               "bg_im2col")
         out = ops.linear(a, pk.w, pk.b, out_dtype=torch.float32, add=residual, add_div=1, n_valid=pk.n)
@@ -281,7 +286,7 @@ class AutoencoderKLFastDecode(_HipVAE):
         S_, H, W, C = shape
         qkv, _ = self._conv(x, shape, P["qkv"], 1, 1, norm=at.group_norm)
         o = torch.empty(S_ * H * W, C, device=x.device, dtype=P["proj"].dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), BG_BF16 if o.dtype == torch.bfloat16 else BG_F32, S_,
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S_,
                                         H * W, C, 1, 1.0 / math.sqrt(C), stream()), "bg_small_attn")
         x = ops.linear(o, P["proj"].w, P["proj"].b, out_dtype=torch.float32, add=x, n_valid=C)
         x, shape = self._resnet(x, shape, P, "m1", d.mid_block.resnets[1])
@@ -300,7 +305,7 @@ class AutoencoderKLFastDecode(_HipVAE):
         z_cl = z.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
         n = z_cl.shape[0]
         side = z_cl.shape[1] * 2 ** (len(self.block_out) - 1)
-        worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (2 if dt == torch.bfloat16 else 4)
+        worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
         out = torch.cat(outs) if len(outs) > 1 else outs[0]
@@ -370,7 +375,7 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         nh = C // 32
         pk = P[f"a{i}proj"]
         o = torch.empty(S * W, C, device=x.device, dtype=pk.dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), BG_BF16 if o.dtype == torch.bfloat16 else BG_F32, S,
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S,
                                         H * W, C, nh, 1.0 / math.sqrt(C // nh), stream()), "bg_small_attn")
         return ops.linear(o, pk.w, pk.b, out_dtype=torch.float32, add=x, n_valid=C)
 
@@ -401,7 +406,7 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         z_cl = z.detach().to(torch.float32).permute(0, 2, 1).contiguous()          # [G, L, 3]
         n = z_cl.shape[0]
         length = z_cl.shape[1] * 2 ** len(self.block_out)
-        worst = length * 5 * self.block_out[-1] * (2 if dt == torch.bfloat16 else 4)
+        worst = length * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
         out = torch.cat(outs) if len(outs) > 1 else outs[0]

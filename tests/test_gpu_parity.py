@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
 
 
 @pytest.fixture(scope="module")
@@ -223,3 +223,51 @@ def test_vae_decode_batch_independence(pc):
         chunked = m(z)
         one = m(z[17:18])
     assert torch.equal(full, chunked) and float((full[17:18] - one).abs().max()) < 1e-5
+
+
+# ---- fp16 operand mode (the reference's own autocast dtype, sample.py:121; BASELINE configs[4]) --------------------
+@pytest.mark.parametrize("shape", [(60, 768, 768), (257, 1024, 768), (1000, 768, 1024), (300, 2304, 768)])
+def test_gemm_fp16_exact_products(pc, shape):
+    assert pc.gemm_case(*shape, F16)["max_abs"] < 2e-5
+    assert pc.gemm_case(*shape, F16, add_mode="resid")["max_abs"] < 2e-5
+    e = pc.gemm_case(*shape, F16, act=1, out_dtype=F16)
+    assert e["max_abs"] < 6e-4 * e["ref_absmax"] + 1e-6                 # fp16 output rounding only (11-bit mantissa)
+
+
+@pytest.mark.parametrize("N", [17, 60, 64, 130, 300])
+def test_attention_fp16(pc, N):
+    e = pc.attn_case(3, N, F16, "ragged")
+    assert e["finite"] and e["max_abs"] < 5e-3 and e["mean_abs"] < 5e-4
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_denoiser_fp16_vs_reference_golden(pc, name):
+    e = pc.golden_case(name, F16)
+    assert e["finite"] and e["max_abs_valid"] < 8e-3 and e["mean_abs"] < 1.5e-3
+
+
+def test_fp16_ddpm_chain_meets_1e3_per_step(pc):
+    e = pc.ddpm_chain_case(F16, steps=50)
+    assert e["finite"] and e["max_abs_eps"] < 8e-3 and e["max_abs_x"] < 2e-3
+    e = pc.ddpm_chain_case(F16, steps=1000, last=12)
+    assert e["finite"] and e["max_abs_x"] < 2e-4
+
+
+def test_autocast_selects_operand_dtype(pc):
+    m, _ = pc.build_net("SurfPosNet", 9, False, None)
+    x, t, _ = pc.synth_inputs("SurfPosNet", 2, 30, 1, False)
+    x, t = x.cuda(), t.cuda()
+    with torch.no_grad():
+        a = m(x, t, None)                                   # no autocast -> exact fp32
+        with torch.autocast("cuda", dtype=torch.float16):
+            b = m(x, t, None)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            c = m(x, t, None)
+    assert set(m._packs) == {torch.float32, torch.float16, torch.bfloat16}
+    assert 0 < float((a - b).abs().max()) < 8e-3 < 1e9 and float((a - b).abs().max()) < float((a - c).abs().max())
+
+
+@pytest.mark.parametrize("kind,n", [("surf", 2), ("edge", 5)])
+def test_vae_decode_fp16(pc, kind, n):
+    e = pc.vae_case(kind, n, F16)
+    assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])
