@@ -10,7 +10,9 @@ All compute goes through libbrepgen_hip.so (hand-written HIP kernels behind a C 
 from .network import EdgePosNet, EdgeZNet, SurfPosNet, SurfZNet  # noqa: F401
 from .schedulers import DDPMScheduler, PNDMScheduler  # noqa: F401
 from .utils import randn_tensor  # noqa: F401
-from .vae import AutoencoderKL1DFastDecode, AutoencoderKLFastDecode  # noqa: F401
+from .vae import (AutoencoderKL1DFastDecode, AutoencoderKL1DFastEncode, AutoencoderKLFastDecode,  # noqa: F401
+                  AutoencoderKLFastEncode)
 
 __all__ = ["SurfPosNet", "SurfZNet", "EdgePosNet", "EdgeZNet", "DDPMScheduler", "PNDMScheduler", "randn_tensor",
-           "AutoencoderKLFastDecode", "AutoencoderKL1DFastDecode"]
+           "AutoencoderKLFastDecode", "AutoencoderKL1DFastDecode", "AutoencoderKLFastEncode",
+           "AutoencoderKL1DFastEncode"]

@@ -64,8 +64,8 @@ _SIGNATURES = {
                                fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp,
                                C.c_size_t, vp]),
     "bg_groupnorm_stats": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
-    "bg_im2col": (C.c_int, [fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp,
-                            C.c_int, C.c_int, fp, vp]),
+    "bg_im2col": (C.c_int, [fp, vp] + [C.c_int] * 13 + [fp, fp, fp, C.c_int, C.c_int, fp, vp]),
+    "bg_downsample1d_cubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_upsample1d_cubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_small_attn": (C.c_int, [fp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_profile_begin": (C.c_int, [C.c_int]),

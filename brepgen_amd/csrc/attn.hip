@@ -37,7 +37,7 @@ template <> struct AElem<true> {
 };
 
 template <int WPH, bool F16>
-__global__ __launch_bounds__(256, 4) void attn16_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
+__global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
                                                         void* __restrict__ out_, int B, int N) {
     using E = AElem<F16>;
     using T = typename E::T;

@@ -53,26 +53,26 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 struct Im2colArgs {
     const float* x; void* out; int out_dtype;
     int S, Hin, Win, C, kh, kw, up;
+    int stride, pad_y, pad_x, Ho, Wo;   // output grid and the padding BEFORE the first row / column (after: zero fill)
     const float* stats; const float* gamma; const float* beta; int G; int act;
     const float* add;        // optional residual, added after norm + activation (1x1 / fp32-out use only)
 };
 
 // one thread = 4 consecutive channels of one (row, tap)
 __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
-    const int H = a.Hin << a.up, W = a.Win << a.up;
+    const int H = a.Hin << a.up, W = a.Win << a.up;       // logical input grid
     const int c4n = a.C >> 2, taps = a.kh * a.kw;
-    const size_t total = (size_t)a.S * H * W * taps * c4n;
-    const int ph = a.kh >> 1, pw = a.kw >> 1;
+    const size_t total = (size_t)a.S * a.Ho * a.Wo * taps * c4n;
     const int cpg = a.stats ? a.C / a.G : 1;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
         size_t r = i / c4n;
         const int tap = (int)(r % taps);
         r /= taps;                                            // row = (s, oy, ox)
-        const int ox = (int)(r % W);
-        const size_t r2 = r / W;
-        const int oy = (int)(r2 % H), s = (int)(r2 / H);
-        const int iy = oy + tap / a.kw - ph, ix = ox + tap % a.kw - pw;
+        const int ox = (int)(r % a.Wo);
+        const size_t r2 = r / a.Wo;
+        const int oy = (int)(r2 % a.Ho), s = (int)(r2 / a.Ho);
+        const int iy = oy * a.stride + tap / a.kw - a.pad_y, ix = ox * a.stride + tap % a.kw - a.pad_x;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
             const int c = c4 * 4;
@@ -103,17 +103,16 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
 // any C (the 3-channel latent inputs of post_quant_conv / conv_in), no norm, fp32 out
 __global__ __launch_bounds__(256) void im2col_scalar_kernel(Im2colArgs a) {
     const int H = a.Hin << a.up, W = a.Win << a.up, taps = a.kh * a.kw;
-    const size_t total = (size_t)a.S * H * W * taps * a.C;
-    const int ph = a.kh >> 1, pw = a.kw >> 1;
+    const size_t total = (size_t)a.S * a.Ho * a.Wo * taps * a.C;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % a.C);
         size_t r = i / a.C;
         const int tap = (int)(r % taps);
         r /= taps;
-        const int ox = (int)(r % W);
-        const size_t r2 = r / W;
-        const int oy = (int)(r2 % H), s = (int)(r2 / H);
-        const int iy = oy + tap / a.kw - ph, ix = ox + tap % a.kw - pw;
+        const int ox = (int)(r % a.Wo);
+        const size_t r2 = r / a.Wo;
+        const int oy = (int)(r2 % a.Ho), s = (int)(r2 / a.Ho);
+        const int iy = oy * a.stride + tap / a.kw - a.pad_y, ix = ox * a.stride + tap % a.kw - a.pad_x;
         float v = 0.f;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)
             v = act_apply(a.x[(((size_t)s * a.Hin + (iy >> a.up)) * a.Win + (ix >> a.up)) * a.C + c], a.act);
@@ -142,6 +141,27 @@ __global__ __launch_bounds__(256) void upsample1d_cubic_kernel(const float* __re
             int j = ii - 2;
             j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);
             acc = fmaf(x[((size_t)s * L + j) * C + c], kCubic2[kk], acc);
+        }
+        y[i] = acc;
+    }
+}
+
+// ---- Downsample1d("cubic") of the edge encoder (diffusers DownBlock1D): reflect-pad 3, depthwise stride-2 conv with
+// the 8-tap cubic kernel: y[o] = sum_k hp[2o + k] * w[k], hp[i] = x[reflect(i - 3)] ----
+__global__ __launch_bounds__(256) void downsample1d_cubic_kernel(const float* __restrict__ x, float* __restrict__ y, int S,
+                                                                 int L, int C) {
+    const int Lo = L >> 1;
+    const size_t total = (size_t)S * Lo * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t r = i / C;
+        const int o = (int)(r % Lo), s = (int)(r / Lo);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int j = 2 * o + k - 3;
+            j = j < 0 ? -j : (j >= L ? 2 * (L - 1) - j : j);
+            acc = fmaf(x[((size_t)s * L + j) * C + c], 0.5f * kCubic2[k], acc);
         }
         y[i] = acc;
     }
@@ -203,17 +223,17 @@ extern "C" int bg_groupnorm_stats(const float* x, float* stats, int S, int P, in
 }
 
 extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hin, int Win, int C, int kh, int kw, int up,
-                         const float* stats, const float* gamma, const float* beta, int G, int act, const float* add,
-                         bg_stream_t stream) {
+                         int stride, int pad_y, int pad_x, int Ho, int Wo, const float* stats, const float* gamma,
+                         const float* beta, int G, int act, const float* add, bg_stream_t stream) {
     BG_REQUIRE(x && out, BG_E_ARG, "bg_im2col: null pointer");
-    BG_REQUIRE(S > 0 && Hin > 0 && Win > 0 && C > 0 && (kh & 1) && (kw & 1) && (up == 0 || up == 1), BG_E_SHAPE,
-               "bg_im2col: bad shape");
+    BG_REQUIRE(S > 0 && Hin > 0 && Win > 0 && C > 0 && kh > 0 && kw > 0 && (up == 0 || up == 1) && stride >= 1 &&
+                   pad_y >= 0 && pad_x >= 0 && Ho > 0 && Wo > 0, BG_E_SHAPE, "bg_im2col: bad shape");
     BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_im2col: out dtype %d", out_dtype);
     BG_REQUIRE(stats == nullptr || (gamma && beta && G > 0 && C % G == 0 && (C / G) % 4 == 0), BG_E_ARG,
                "bg_im2col: normalisation needs gamma, beta and (C/G) %% 4 == 0");
     BG_REQUIRE(add == nullptr || (kh == 1 && kw == 1 && C % 4 == 0), BG_E_ARG, "bg_im2col: residual add needs a 1x1 window");
-    bg::Im2colArgs a{x, out, out_dtype, S, Hin, Win, C, kh, kw, up, stats, gamma, beta, G, act, add};
-    const size_t rows = (size_t)S * (Hin << up) * (Win << up);
+    bg::Im2colArgs a{x, out, out_dtype, S, Hin, Win, C, kh, kw, up, stride, pad_y, pad_x, Ho, Wo, stats, gamma, beta, G, act, add};
+    const size_t rows = (size_t)S * Ho * Wo;
     bg::ProfScope prof(bg::PK_MISC, 0.0, rows * (double)kh * kw * C * (4.0 + (out_dtype == BG_F32 ? 4.0 : 2.0)),
                        (hipStream_t)stream);
     if (C % 4 == 0) {
@@ -231,6 +251,14 @@ extern "C" int bg_upsample1d_cubic(const float* x, float* y, int S, int L, int C
     hipLaunchKernelGGL(bg::upsample1d_cubic_kernel, dim3(bg::cap_grid((size_t)S * 2 * L * C)), dim3(256), 0, (hipStream_t)stream,
                        x, y, S, L, C);
     return bg::launch_status("upsample1d_cubic");
+}
+
+extern "C" int bg_downsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream) {
+    BG_REQUIRE(x && y && S > 0 && L >= 4 && (L & 1) == 0 && C > 0, BG_E_ARG, "bg_downsample1d_cubic: bad arguments (even L >= 4)");
+    bg::ProfScope prof(bg::PK_MISC, 0.0, 6.0 * S * (double)L * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bg::downsample1d_cubic_kernel, dim3(bg::cap_grid((size_t)S * (L / 2) * C)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, S, L, C);
+    return bg::launch_status("downsample1d_cubic");
 }
 
 extern "C" int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype, int S, int T, int C, int nh, float scale,

@@ -203,20 +203,93 @@ class _HipVAE(nn.Module):
               "bg_groupnorm_stats")
         return st
 
-    def _conv(self, x, shape, pk, kh, kw, up=0, norm=None, act=ACT_NONE, residual=None):
+    def _conv(self, x, shape, pk, kh, kw, up=0, norm=None, act=ACT_NONE, residual=None, stride=1, pad=None):
+        """conv (kh x kw) on channels-last x; pad=None: 'same' (kh//2, kw//2); pad=(py, px): zeros before only."""
         S, H, W, C = shape
         lib = _lib.load()
-        Ho, Wo = H << up, W << up
+        Hl, Wl = H << up, W << up
+        if pad is None:
+            py, px = kh // 2, kw // 2
+            Ho, Wo = (Hl + 2 * py - kh) // stride + 1, (Wl + 2 * px - kw) // stride + 1
+        else:                                          # Downsample2D: F.pad(x, (0,1,0,1)) then stride-2 conv, no padding
+            py, px = pad
+            Ho, Wo = (Hl + 1 - kh) // stride + 1 if kh > 1 else Hl, (Wl + 1 - kw) // stride + 1
         rows = S * Ho * Wo
         a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
         st = self._stats(x, S, H * W, C, norm) if norm is not None else None
         g = norm.weight.detach().float().contiguous() if norm is not None else None
         b = norm.bias.detach().float().contiguous() if norm is not None else None
-        check(lib.bg_im2col(ptr(x), ptr(a), _CODE[pk.dtype], S, H, W, C, kh, kw, up,
+        check(lib.bg_im2col(ptr(x), ptr(a), _CODE[pk.dtype], S, H, W, C, kh, kw, up, stride, py, px, Ho, Wo,
                             ptr(st), ptr(g), ptr(b), norm.num_groups if norm is not None else 1, act, None, stream()),
               "bg_im2col")
         out = ops.linear(a, pk.w, pk.b, out_dtype=torch.float32, add=residual, add_div=1, n_valid=pk.n)
         return out, (S, Ho, Wo, pk.n)
+
+    def _resnet(self, x, shape, P, name, r):
+        S, H, W, C = shape
+        h, hs = self._conv(x, shape, P[name + "c1"], 3, 3, norm=r.norm1, act=ACT_SILU)
+        if name + "sc" in P:
+            x, _ = self._conv(x, shape, P[name + "sc"], 1, 1)
+        out, os_ = self._conv(h, hs, P[name + "c2"], 3, 3, norm=r.norm2, act=ACT_SILU, residual=x)
+        return out, os_
+
+    def _attn2d(self, x, shape, P, key, at):
+        """diffusers Attention of the 2-D mid block: 1 head over H*W tokens, dim_head = C."""
+        S_, H, W, C = shape
+        qkv, _ = self._conv(x, shape, P[key + "qkv"], 1, 1, norm=at.group_norm)
+        o = torch.empty(S_ * H * W, C, device=x.device, dtype=P[key + "proj"].dtype)
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S_, H * W, C, 1, 1.0 / math.sqrt(C),
+                                        stream()), "bg_small_attn")
+        return ops.linear(o, P[key + "proj"].w, P[key + "proj"].b, out_dtype=torch.float32, add=x, n_valid=C)
+
+    def _pack_resnet2d(self, P, name, r, dt):
+        P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv1, dt), self._pack_conv(r.conv2, dt)
+        if hasattr(r, "conv_shortcut"):
+            P[name + "sc"] = self._pack_conv(r.conv_shortcut, dt)
+
+    def _pack_attn2d(self, P, key, at, dt):
+        P[key + "qkv"] = self._pack_gemm(torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight]),
+                                         torch.cat([at.to_q.bias, at.to_k.bias, at.to_v.bias]), dt)
+        P[key + "proj"] = self._pack_gemm(at.to_out[0].weight, at.to_out[0].bias, dt)
+
+    def _pack_resconv(self, P, name, r, dt):
+        P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv_1, dt), self._pack_conv(r.conv_2, dt)
+        if hasattr(r, "conv_skip"):
+            P[name + "sk"] = self._pack_conv(r.conv_skip, dt)
+
+    def _pack_attn1d(self, P, key, at, dt):
+        P[key + "qkv"] = self._pack_gemm(torch.cat([at.query.weight, at.key.weight, at.value.weight]),
+                                         torch.cat([at.query.bias, at.key.bias, at.value.bias]), dt)
+        P[key + "proj"] = self._pack_gemm(at.proj_attn.weight, at.proj_attn.bias, dt)
+
+    def _resconv(self, x, shape, P, name, r):
+        # ResConvBlock: conv k5 -> GroupNorm(1) -> GELU -> conv k5 -> GroupNorm(1) -> GELU, + (1x1) skip.
+        # group_norm_1 + GELU fold into the gather of conv_2; the trailing group_norm_2 + GELU cannot fold into the
+        # next consumer (the residual add sits in between), so it is one 1x1 "im2col" pass with the add fused.
+        h, hs = self._conv(x, shape, P[name + "c1"], 1, 5)
+        h, hs = self._conv(h, hs, P[name + "c2"], 1, 5, norm=r.group_norm_1, act=ACT_GELU)
+        S, H, W, C = hs
+        res = x
+        if name + "sk" in P:
+            res, _ = self._conv(x, shape, P[name + "sk"], 1, 1)
+        st = self._stats(h, S, H * W, C, r.group_norm_2)
+        y = torch.empty(S * H * W, C, device=h.device, dtype=torch.float32)
+        check(_lib.load().bg_im2col(ptr(h), ptr(y), BG_F32, S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st),
+                                    ptr(r.group_norm_2.weight.detach().float().contiguous()),
+                                    ptr(r.group_norm_2.bias.detach().float().contiguous()), 1, ACT_GELU,
+                                    ptr(res.contiguous()), stream()),
+              "bg_im2col[norm+gelu+residual]")
+        return y, hs
+
+    def _attn1d(self, x, shape, P, key, at):
+        S, H, W, C = shape
+        qkv, _ = self._conv(x, shape, P[key + "qkv"], 1, 1, norm=at.group_norm)
+        nh = C // 32
+        pk = P[key + "proj"]
+        o = torch.empty(S * W, C, device=x.device, dtype=pk.dtype)
+        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S,
+                                        H * W, C, nh, 1.0 / math.sqrt(C // nh), stream()), "bg_small_attn")
+        return ops.linear(o, pk.w, pk.b, out_dtype=torch.float32, add=x, n_valid=C)
 
     def _chunk(self, n, per_sample_bytes):
         return max(1, min(n, self.IM2COL_BUDGET // max(1, per_sample_bytes)))
@@ -243,34 +316,17 @@ class AutoencoderKLFastDecode(_HipVAE):
         d = self.decoder
         P["pq"] = self._pack_conv(self.post_quant_conv, dt)
         P["in"] = self._pack_conv(d.conv_in, dt)
-
-        def resnet(name, r):
-            P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv1, dt), self._pack_conv(r.conv2, dt)
-            if hasattr(r, "conv_shortcut"):
-                P[name + "sc"] = self._pack_conv(r.conv_shortcut, dt)
-
-        resnet("m0", d.mid_block.resnets[0])
-        resnet("m1", d.mid_block.resnets[1])
-        at = d.mid_block.attentions[0]
-        P["qkv"] = self._pack_gemm(torch.cat([at.to_q.weight, at.to_k.weight, at.to_v.weight]),
-                                   torch.cat([at.to_q.bias, at.to_k.bias, at.to_v.bias]), dt)
-        P["proj"] = self._pack_gemm(at.to_out[0].weight, at.to_out[0].bias, dt)
+        self._pack_resnet2d(P, "m0", d.mid_block.resnets[0], dt)
+        self._pack_resnet2d(P, "m1", d.mid_block.resnets[1], dt)
+        self._pack_attn2d(P, "ma", d.mid_block.attentions[0], dt)
         for bi, blk in enumerate(d.up_blocks):
             for ri, r in enumerate(blk.resnets):
-                resnet(f"u{bi}r{ri}", r)
+                self._pack_resnet2d(P, f"u{bi}r{ri}", r, dt)
             if hasattr(blk, "upsamplers"):
                 P[f"u{bi}up"] = self._pack_conv(blk.upsamplers[0].conv, dt)
         P["out"] = self._pack_conv(d.conv_out, dt)
         self._packs[dt] = P
         return P
-
-    def _resnet(self, x, shape, P, name, r):
-        S, H, W, C = shape
-        h, hs = self._conv(x, shape, P[name + "c1"], 3, 3, norm=r.norm1, act=ACT_SILU)
-        if name + "sc" in P:
-            x, _ = self._conv(x, shape, P[name + "sc"], 1, 1)
-        out, os_ = self._conv(h, hs, P[name + "c2"], 3, 3, norm=r.norm2, act=ACT_SILU, residual=x)
-        return out, os_
 
     def _decode_chunk(self, z_cl, dt):
         """z_cl: channels-last fp32 [S,4,4,latent] -> [S,32,32,out]."""
@@ -281,14 +337,7 @@ class AutoencoderKLFastDecode(_HipVAE):
         x, shape = self._conv(z_cl, shape, P["pq"], 1, 1)
         x, shape = self._conv(x, shape, P["in"], 3, 3)
         x, shape = self._resnet(x, shape, P, "m0", d.mid_block.resnets[0])
-        # mid-block attention (1 head over H*W tokens, dim_head = C)
-        at = d.mid_block.attentions[0]
-        S_, H, W, C = shape
-        qkv, _ = self._conv(x, shape, P["qkv"], 1, 1, norm=at.group_norm)
-        o = torch.empty(S_ * H * W, C, device=x.device, dtype=P["proj"].dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S_,
-                                        H * W, C, 1, 1.0 / math.sqrt(C), stream()), "bg_small_attn")
-        x = ops.linear(o, P["proj"].w, P["proj"].b, out_dtype=torch.float32, add=x, n_valid=C)
+        x = self._attn2d(x, shape, P, "ma", d.mid_block.attentions[0])
         x, shape = self._resnet(x, shape, P, "m1", d.mid_block.resnets[1])
         for bi, blk in enumerate(d.up_blocks):
             for ri, r in enumerate(blk.resnets):
@@ -331,53 +380,15 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         d = self.decoder
         P["pq"] = self._pack_conv(self.post_quant_conv, dt)
         P["in"] = self._pack_conv(d.conv_in, dt)
-
-        def resconv(name, r):
-            P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv_1, dt), self._pack_conv(r.conv_2, dt)
-            if hasattr(r, "conv_skip"):
-                P[name + "sk"] = self._pack_conv(r.conv_skip, dt)
-
         for i in range(6):
-            resconv(f"m{i}", d.mid_block.resnets[i])
-            at = d.mid_block.attentions[i]
-            P[f"a{i}qkv"] = self._pack_gemm(torch.cat([at.query.weight, at.key.weight, at.value.weight]),
-                                            torch.cat([at.query.bias, at.key.bias, at.value.bias]), dt)
-            P[f"a{i}proj"] = self._pack_gemm(at.proj_attn.weight, at.proj_attn.bias, dt)
+            self._pack_resconv(P, f"m{i}", d.mid_block.resnets[i], dt)
+            self._pack_attn1d(P, f"a{i}", d.mid_block.attentions[i], dt)
         for bi, blk in enumerate(d.up_blocks):
             for ri, r in enumerate(blk.resnets):
-                resconv(f"u{bi}r{ri}", r)
+                self._pack_resconv(P, f"u{bi}r{ri}", r, dt)
         P["out"] = self._pack_conv(d.conv_out, dt)
         self._packs[dt] = P
         return P
-
-    def _resconv(self, x, shape, P, name, r):
-        # ResConvBlock: conv k5 -> GroupNorm(1) -> GELU -> conv k5 -> GroupNorm(1) -> GELU, + (1x1) skip.
-        # group_norm_1 + GELU fold into the gather of conv_2; the trailing group_norm_2 + GELU cannot fold into the
-        # next consumer (the residual add sits in between), so it is one 1x1 "im2col" pass with the add fused.
-        h, hs = self._conv(x, shape, P[name + "c1"], 1, 5)
-        h, hs = self._conv(h, hs, P[name + "c2"], 1, 5, norm=r.group_norm_1, act=ACT_GELU)
-        S, H, W, C = hs
-        res = x
-        if name + "sk" in P:
-            res, _ = self._conv(x, shape, P[name + "sk"], 1, 1)
-        st = self._stats(h, S, H * W, C, r.group_norm_2)
-        y = torch.empty(S * H * W, C, device=h.device, dtype=torch.float32)
-        check(_lib.load().bg_im2col(ptr(h), ptr(y), BG_F32, S, H, W, C, 1, 1, 0, ptr(st),
-                                    ptr(r.group_norm_2.weight.detach().float().contiguous()),
-                                    ptr(r.group_norm_2.bias.detach().float().contiguous()), 1, ACT_GELU,
-                                    ptr(res.contiguous()), stream()),
-              "bg_im2col[norm+gelu+residual]")
-        return y, hs
-
-    def _attn(self, x, shape, P, i, at):
-        S, H, W, C = shape
-        qkv, _ = self._conv(x, shape, P[f"a{i}qkv"], 1, 1, norm=at.group_norm)
-        nh = C // 32
-        pk = P[f"a{i}proj"]
-        o = torch.empty(S * W, C, device=x.device, dtype=pk.dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S,
-                                        H * W, C, nh, 1.0 / math.sqrt(C // nh), stream()), "bg_small_attn")
-        return ops.linear(o, pk.w, pk.b, out_dtype=torch.float32, add=x, n_valid=C)
 
     def _decode_chunk(self, z_cl, dt):
         P = self._pack(dt)
@@ -388,7 +399,7 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         x, shape = self._conv(x, shape, P["in"], 1, 3)
         for i in range(6):
             x, shape = self._resconv(x, shape, P, f"m{i}", d.mid_block.resnets[i])
-            x = self._attn(x, shape, P, i, d.mid_block.attentions[i])
+            x = self._attn1d(x, shape, P, f"a{i}", d.mid_block.attentions[i])
         for bi, blk in enumerate(d.up_blocks):
             for ri, r in enumerate(blk.resnets):
                 x, shape = self._resconv(x, shape, P, f"u{bi}r{ri}", r)
@@ -409,5 +420,181 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         worst = length * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
+        out = torch.cat(outs) if len(outs) > 1 else outs[0]
+        return out.permute(0, 2, 1).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# encoders (training-time API surface of the path: trainer.py:521,925 call FastEncode under no_grad)
+# --------------------------------------------------------------------------------------------------
+class _Down2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+
+class _DownBlock2D(nn.Module):
+    def __init__(self, cin, cout, n, groups, downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet2D(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        if downsample:
+            self.downsamplers = nn.ModuleList([_Down2D(cout)])
+
+
+class _Encoder2D(nn.Module):
+    def __init__(self, in_ch, latent, block_out, layers_per_block, groups):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_ch, block_out[0], 3, padding=1)
+        blocks, prev = [], block_out[0]
+        for i, ch in enumerate(block_out):
+            blocks.append(_DownBlock2D(prev, ch, layers_per_block, groups, downsample=i != len(block_out) - 1))
+            prev = ch
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _Mid2D(block_out[-1], groups)
+        self.conv_norm_out = nn.GroupNorm(groups, block_out[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(block_out[-1], 2 * latent, 3, padding=1)
+
+
+class _CubicDown(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("kernel", torch.tensor(CUBIC2) / 2)
+
+
+class _DownBlock1D(nn.Module):                     # diffusers DownBlock1D(out_channels, in_channels)
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.down = _CubicDown()
+        self.resnets = nn.ModuleList([_ResConv(cin, cout, cout), _ResConv(cout, cout, cout), _ResConv(cout, cout, cout)])
+
+
+class _Encoder1D(nn.Module):                       # network.py:86-185
+    def __init__(self, in_ch, latent, block_out, groups):
+        super().__init__()
+        self.conv_in = nn.Conv1d(in_ch, block_out[0], 3, padding=1)
+        blocks, prev = [], block_out[0]
+        for ch in block_out:
+            blocks.append(_DownBlock1D(prev, ch))
+            prev = ch
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _Mid1D(block_out[-1])
+        self.conv_norm_out = nn.GroupNorm(groups, block_out[-1], eps=1e-6)
+        self.conv_out = nn.Conv1d(block_out[-1], 2 * latent, 3, padding=1)
+
+
+class AutoencoderKLFastEncode(_HipVAE):
+    """Surface-VAE encoder: points [F,3,32,32] -> posterior mode [F,3,4,4]  (network.py:861-945)."""
+
+    def __init__(self, in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",),
+                 up_block_types=("UpDecoderBlock2D",), block_out_channels=(64,), layers_per_block=1, act_fn="silu",
+                 latent_channels=4, norm_num_groups=32, sample_size=32, scaling_factor=0.18215, force_upcast=True):
+        super().__init__()
+        self.block_out, self.latent, self.in_ch = tuple(block_out_channels), latent_channels, in_channels
+        self.encoder = _Encoder2D(in_channels, latent_channels, self.block_out, layers_per_block, norm_num_groups)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+
+    def _pack(self, dt):
+        if dt in self._packs:
+            return self._packs[dt]
+        P, e = {}, self.encoder
+        P["in"] = self._pack_conv(e.conv_in, dt)
+        for bi, blk in enumerate(e.down_blocks):
+            for ri, r in enumerate(blk.resnets):
+                self._pack_resnet2d(P, f"d{bi}r{ri}", r, dt)
+            if hasattr(blk, "downsamplers"):
+                P[f"d{bi}dn"] = self._pack_conv(blk.downsamplers[0].conv, dt)
+        self._pack_resnet2d(P, "m0", e.mid_block.resnets[0], dt)
+        self._pack_resnet2d(P, "m1", e.mid_block.resnets[1], dt)
+        self._pack_attn2d(P, "ma", e.mid_block.attentions[0], dt)
+        P["out"] = self._pack_conv(e.conv_out, dt)
+        P["q"] = self._pack_conv(self.quant_conv, dt)
+        self._packs[dt] = P
+        return P
+
+    def _encode_chunk(self, x_cl, dt):
+        P, e = self._pack(dt), self.encoder
+        S = x_cl.shape[0]
+        shape = (S, x_cl.shape[1], x_cl.shape[2], self.in_ch)
+        x, shape = self._conv(x_cl, shape, P["in"], 3, 3)
+        for bi, blk in enumerate(e.down_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x, shape = self._resnet(x, shape, P, f"d{bi}r{ri}", r)
+            if hasattr(blk, "downsamplers"):                      # Downsample2D: pad (0,1,0,1), conv 3x3 stride 2
+                x, shape = self._conv(x, shape, P[f"d{bi}dn"], 3, 3, stride=2, pad=(0, 0))
+        x, shape = self._resnet(x, shape, P, "m0", e.mid_block.resnets[0])
+        x = self._attn2d(x, shape, P, "ma", e.mid_block.attentions[0])
+        x, shape = self._resnet(x, shape, P, "m1", e.mid_block.resnets[1])
+        x, shape = self._conv(x, shape, P["out"], 3, 3, norm=e.conv_norm_out, act=ACT_SILU)
+        x, shape = self._conv(x, shape, P["q"], 1, 1)
+        return x.reshape(shape)[..., : self.latent]               # DiagonalGaussianDistribution(moments).mode() = mean
+
+    def forward(self, x, return_dict=True):
+        if not x.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {x.device})")
+        dt = self._dtype()
+        x_cl = x.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        n, side = x_cl.shape[0], x_cl.shape[1]
+        worst = side * side * 9 * self.block_out[0] * (4 if dt == torch.float32 else 2)
+        step = self._chunk(n, worst)
+        outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
+        out = torch.cat(outs) if len(outs) > 1 else outs[0]
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
+class AutoencoderKL1DFastEncode(_HipVAE):
+    """Edge-VAE encoder: points [G,3,32] -> posterior mode [G,3,4]  (network.py:690-783)."""
+
+    def __init__(self, in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",),
+                 up_block_types=("UpDecoderBlock2D",), block_out_channels=(64,), layers_per_block=1, act_fn="silu",
+                 latent_channels=4, norm_num_groups=32, sample_size=32, scaling_factor=0.18215):
+        super().__init__()
+        self.block_out, self.latent, self.in_ch = tuple(block_out_channels), latent_channels, in_channels
+        self.encoder = _Encoder1D(in_channels, latent_channels, self.block_out, norm_num_groups)
+        self.quant_conv = nn.Conv1d(2 * latent_channels, 2 * latent_channels, 1)
+
+    def _pack(self, dt):
+        if dt in self._packs:
+            return self._packs[dt]
+        P, e = {}, self.encoder
+        P["in"] = self._pack_conv(e.conv_in, dt)
+        for bi, blk in enumerate(e.down_blocks):
+            for ri, r in enumerate(blk.resnets):
+                self._pack_resconv(P, f"d{bi}r{ri}", r, dt)
+        for i in range(6):
+            self._pack_resconv(P, f"m{i}", e.mid_block.resnets[i], dt)
+            self._pack_attn1d(P, f"a{i}", e.mid_block.attentions[i], dt)
+        P["out"] = self._pack_conv(e.conv_out, dt)
+        P["q"] = self._pack_conv(self.quant_conv, dt)
+        self._packs[dt] = P
+        return P
+
+    def _encode_chunk(self, x_cl, dt):
+        P, e = self._pack(dt), self.encoder
+        S, L = x_cl.shape[0], x_cl.shape[1]
+        shape = (S, 1, L, self.in_ch)
+        x, shape = self._conv(x_cl, shape, P["in"], 1, 3)
+        for bi, blk in enumerate(e.down_blocks):
+            S_, _, L_, C = shape
+            y = torch.empty(S_ * (L_ // 2), C, device=x.device, dtype=torch.float32)
+            check(_lib.load().bg_downsample1d_cubic(ptr(x), ptr(y), S_, L_, C, stream()), "bg_downsample1d_cubic")
+            x, shape = y, (S_, 1, L_ // 2, C)
+            for ri, r in enumerate(blk.resnets):
+                x, shape = self._resconv(x, shape, P, f"d{bi}r{ri}", r)
+        for i in range(6):
+            x, shape = self._resconv(x, shape, P, f"m{i}", e.mid_block.resnets[i])
+            x = self._attn1d(x, shape, P, f"a{i}", e.mid_block.attentions[i])
+        x, shape = self._conv(x, shape, P["out"], 1, 3, norm=e.conv_norm_out, act=ACT_SILU)
+        x, shape = self._conv(x, shape, P["q"], 1, 1)
+        return x.reshape(shape[0], shape[2], shape[3])[..., : self.latent]
+
+    def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
+        if not sample.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {sample.device})")
+        dt = self._dtype()
+        x_cl = sample.detach().to(torch.float32).permute(0, 2, 1).contiguous()
+        n = x_cl.shape[0]
+        worst = x_cl.shape[1] * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
+        step = self._chunk(n, worst)
+        outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
         out = torch.cat(outs) if len(outs) > 1 else outs[0]
         return out.permute(0, 2, 1).contiguous()

@@ -169,18 +169,23 @@ int bg_pndm_step(const float* eps_c, const float* eps_u, float guidance_w, const
 int bg_groupnorm_stats(const float* x, float* stats /*[S,G,2]*/, int S, int P, int C, int G, float eps,
                        bg_stream_t stream);
 
-/* im2col of a (kh x kw, stride 1, zero-pad kh/2, kw/2) convolution over the grid (Hin << up, Win << up), with
+/* im2col of a kh x kw convolution with `stride`, over the logical input grid (Hin << up, Win << up), producing
+ * an Ho x Wo output grid; `pad_y` / `pad_x` zeros precede the first row / column, whatever the window needs beyond
+ * the last row / column is zero as well (covers pad=1 convs, and Downsample2D's F.pad(0,1,0,1) + stride 2).  With
  *   - optional nearest x2 up-sampling of the source (Upsample2D) folded in (up = 1),
  *   - optional GroupNorm (stats from bg_groupnorm_stats, gamma, beta) and activation (0 none, 1 SiLU, 2 GELU-erf)
  *     applied on the fly (ResnetBlock2D / ResConvBlock / conv_norm_out),
- *   - optional residual `add` [S*H*W, C] added after the activation (1x1 window only: the tail of ResConvBlock).
- * out: [S*H*W, kh*kw*C] fp32 or bf16, tap-major / channel-minor. */
+ *   - optional residual `add` [S*Ho*Wo, C] added after the activation (1x1 window only: the tail of ResConvBlock).
+ * out: [S*Ho*Wo, kh*kw*C] fp32 / bf16 / fp16, tap-major / channel-minor. */
 int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hin, int Win, int C, int kh, int kw, int up,
-              const float* stats, const float* gamma, const float* beta, int G, int act, const float* add,
-              bg_stream_t stream);
+              int stride, int pad_y, int pad_x, int Ho, int Wo, const float* stats, const float* gamma,
+              const float* beta, int G, int act, const float* add, bg_stream_t stream);
 
 /* diffusers Upsample1d("cubic") (network.py:43): x [S,L,C] -> y [S,2L,C], reflect pad + 8-tap transposed conv. */
 int bg_upsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream);
+
+/* diffusers Downsample1d("cubic") of the edge encoder (network.py:86-185 via get_down_block): [S,L,C] -> [S,L/2,C]. */
+int bg_downsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream);
 
 /* Self-attention of the VAE mid blocks (diffusers Attention with 1 head over 16 tokens; SelfAttention1d with
  * C/32 heads over 4 tokens): qkv fp32 [S*T, ld] with q|k|v at columns 0, C, 2C; out [S*T, C] fp32 or bf16. */

@@ -207,6 +207,117 @@ def edge_decoder_spec(block_out=(128, 256, 512), latent=3, out_ch=3):
     return spec
 
 
+# ------------------------------------------------------------------------------------------------
+# encoders (training-time API surface: AutoencoderKLFastEncode network.py:861-945, AutoencoderKL1DFastEncode 690-783)
+# ------------------------------------------------------------------------------------------------
+def surf_encode(sd, x, n_down=4, layers_per_block=2, groups=32, latent=3):
+    """AutoencoderKLFastEncode.forward: x [F,3,32,32] -> DiagonalGaussian mode [F,3,4,4] (network.py:941-945)."""
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for b in range(n_down):
+        for r in range(layers_per_block):
+            h = _resnet2d(sd, f"encoder.down_blocks.{b}.resnets.{r}.", h, groups)
+        key = f"encoder.down_blocks.{b}.downsamplers.0.conv."
+        if key + "weight" in sd:                                             # Downsample2D(padding=0): pad (0,1,0,1)
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[key + "weight"], sd[key + "bias"], stride=2)
+    h = _resnet2d(sd, "encoder.mid_block.resnets.0.", h, groups)
+    h = _attn2d(sd, "encoder.mid_block.attentions.0.", h, groups)
+    h = _resnet2d(sd, "encoder.mid_block.resnets.1.", h, groups)
+    h = F.group_norm(h, groups, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], 1e-6)
+    h = F.conv2d(F.silu(h), sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    moments = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    return moments[:, :latent]                                                # mode() = mean
+
+
+def surf_encoder_spec(block_out=(128, 256, 512, 512), layers_per_block=2, latent=3, in_ch=3):
+    spec = {"quant_conv.weight": (2 * latent, 2 * latent, 1, 1), "quant_conv.bias": (2 * latent,)}
+    spec["encoder.conv_in.weight"] = (block_out[0], in_ch, 3, 3); spec["encoder.conv_in.bias"] = (block_out[0],)
+
+    def resnet(p, cin, cout):
+        spec[p + "norm1.weight"] = (cin,); spec[p + "norm1.bias"] = (cin,)
+        spec[p + "conv1.weight"] = (cout, cin, 3, 3); spec[p + "conv1.bias"] = (cout,)
+        spec[p + "norm2.weight"] = (cout,); spec[p + "norm2.bias"] = (cout,)
+        spec[p + "conv2.weight"] = (cout, cout, 3, 3); spec[p + "conv2.bias"] = (cout,)
+        if cin != cout:
+            spec[p + "conv_shortcut.weight"] = (cout, cin, 1, 1); spec[p + "conv_shortcut.bias"] = (cout,)
+
+    prev = block_out[0]
+    for b, ch in enumerate(block_out):
+        for r in range(layers_per_block):
+            resnet(f"encoder.down_blocks.{b}.resnets.{r}.", prev if r == 0 else ch, ch)
+        if b != len(block_out) - 1:
+            spec[f"encoder.down_blocks.{b}.downsamplers.0.conv.weight"] = (ch, ch, 3, 3)
+            spec[f"encoder.down_blocks.{b}.downsamplers.0.conv.bias"] = (ch,)
+        prev = ch
+    top = block_out[-1]
+    resnet("encoder.mid_block.resnets.0.", top, top)
+    a = "encoder.mid_block.attentions.0."
+    spec[a + "group_norm.weight"] = (top,); spec[a + "group_norm.bias"] = (top,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        spec[a + n + ".weight"] = (top, top); spec[a + n + ".bias"] = (top,)
+    resnet("encoder.mid_block.resnets.1.", top, top)
+    spec["encoder.conv_norm_out.weight"] = (top,); spec["encoder.conv_norm_out.bias"] = (top,)
+    spec["encoder.conv_out.weight"] = (2 * latent, top, 3, 3); spec["encoder.conv_out.bias"] = (2 * latent,)
+    return spec
+
+
+def downsample1d_cubic(x):
+    """diffusers Downsample1d("cubic"): reflect pad 3, dense-diagonal stride-2 conv with the 8-tap kernel."""
+    C = x.shape[1]
+    k = torch.tensor(CUBIC, dtype=x.dtype)
+    xp = F.pad(x, (3, 3), mode="reflect")
+    w = x.new_zeros(C, C, 8)
+    idx = torch.arange(C)
+    w[idx, idx] = k
+    return F.conv1d(xp, w, stride=2)
+
+
+def edge_encode(sd, x, n_down=3, latent=3):
+    """AutoencoderKL1DFastEncode.forward: x [G,3,32] -> mode [G,3,4] (network.py:765-783; Encoder1D 86-185)."""
+    h = F.conv1d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    for b in range(n_down):                                                   # DownBlock1D: down, then 3 ResConvBlocks
+        h = downsample1d_cubic(h)
+        for r in range(3):
+            h = _resconv(sd, f"encoder.down_blocks.{b}.resnets.{r}.", h)
+    for i in range(6):
+        h = _resconv(sd, f"encoder.mid_block.resnets.{i}.", h)
+        h = _attn1d(sd, f"encoder.mid_block.attentions.{i}.", h)
+    h = F.group_norm(h, 32, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], 1e-6)
+    h = F.conv1d(F.silu(h), sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    moments = F.conv1d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    return moments[:, :latent]
+
+
+def edge_encoder_spec(block_out=(128, 256, 512), latent=3, in_ch=3):
+    spec = {"quant_conv.weight": (2 * latent, 2 * latent, 1), "quant_conv.bias": (2 * latent,)}
+    spec["encoder.conv_in.weight"] = (block_out[0], in_ch, 3); spec["encoder.conv_in.bias"] = (block_out[0],)
+
+    def resconv(p, cin, mid, cout):
+        if cin != cout:
+            spec[p + "conv_skip.weight"] = (cout, cin, 1)
+        spec[p + "conv_1.weight"] = (mid, cin, 5); spec[p + "conv_1.bias"] = (mid,)
+        spec[p + "group_norm_1.weight"] = (mid,); spec[p + "group_norm_1.bias"] = (mid,)
+        spec[p + "conv_2.weight"] = (cout, mid, 5); spec[p + "conv_2.bias"] = (cout,)
+        spec[p + "group_norm_2.weight"] = (cout,); spec[p + "group_norm_2.bias"] = (cout,)
+
+    prev = block_out[0]
+    for b, ch in enumerate(block_out):                                       # DownBlock1D(out_channels=ch, in_channels=prev)
+        spec[f"encoder.down_blocks.{b}.down.kernel"] = (8,)
+        resconv(f"encoder.down_blocks.{b}.resnets.0.", prev, ch, ch)
+        resconv(f"encoder.down_blocks.{b}.resnets.1.", ch, ch, ch)
+        resconv(f"encoder.down_blocks.{b}.resnets.2.", ch, ch, ch)
+        prev = ch
+    top = block_out[-1]
+    for i in range(6):
+        resconv(f"encoder.mid_block.resnets.{i}.", top, top, top)
+        a = f"encoder.mid_block.attentions.{i}."
+        spec[a + "group_norm.weight"] = (top,); spec[a + "group_norm.bias"] = (top,)
+        for n in ("query", "key", "value", "proj_attn"):
+            spec[a + n + ".weight"] = (top, top); spec[a + n + ".bias"] = (top,)
+    spec["encoder.conv_norm_out.weight"] = (top,); spec["encoder.conv_norm_out.bias"] = (top,)
+    spec["encoder.conv_out.weight"] = (2 * latent, top, 3); spec["encoder.conv_out.bias"] = (2 * latent,)
+    return spec
+
+
 def seeded_state_dict(spec, seed):
     """Deterministic synthetic weights: conv/linear ~ N(0, 1/fan_in), norm gains 1 + N(0, 0.1^2), biases N(0, 0.02^2)."""
     g = torch.Generator().manual_seed(seed)
@@ -214,6 +325,8 @@ def seeded_state_dict(spec, seed):
     for key, shape in spec.items():
         if key.endswith("up.kernel"):
             sd[key] = torch.tensor(CUBIC) * 2
+        elif key.endswith("down.kernel"):
+            sd[key] = torch.tensor(CUBIC)
         elif len(shape) >= 2:
             fan_in = 1
             for s in shape[1:]:

@@ -286,6 +286,18 @@ def vae_case(kind, n, dtype, seed=0):
         z = torch.randn(n, 3, 4, 4, generator=g)
         with torch.no_grad():
             want = ov.surf_decode(sd, z)
+    elif kind == "surf_enc":
+        sd = ov.seeded_state_dict(ov.surf_encoder_spec(), 51 + seed)
+        m = bga.AutoencoderKLFastEncode(**SURF_CFG)
+        z = torch.randn(n, 3, 32, 32, generator=g)
+        with torch.no_grad():
+            want = ov.surf_encode(sd, z)
+    elif kind == "edge_enc":
+        sd = ov.seeded_state_dict(ov.edge_encoder_spec(), 61 + seed)
+        m = bga.AutoencoderKL1DFastEncode(**EDGE_CFG)
+        z = torch.randn(n, 3, 32, generator=g)
+        with torch.no_grad():
+            want = ov.edge_encode(sd, z)
     else:
         sd = ov.seeded_state_dict(ov.edge_decoder_spec(), 41 + seed)
         m = bga.AutoencoderKL1DFastDecode(**EDGE_CFG)
@@ -310,4 +322,16 @@ def upsample1d_case(S=3, L=8, C=12):
     xc = x.permute(0, 2, 1).contiguous().to(DEV)
     y = torch.empty(S, 2 * L, C, device=DEV)
     _lib.check(_lib.load().bg_upsample1d_cubic(xc.data_ptr(), y.data_ptr(), S, L, C, _lib.stream()), "upsample")
+    return _err(y.permute(0, 2, 1), want)
+
+
+def downsample1d_case(S=3, L=16, C=12):
+    from oracle import vae as ov
+    from brepgen_amd import _lib
+    g = gen(6)
+    x = torch.randn(S, C, L, generator=g)
+    want = ov.downsample1d_cubic(x)
+    xc = x.permute(0, 2, 1).contiguous().to(DEV)
+    y = torch.empty(S, L // 2, C, device=DEV)
+    _lib.check(_lib.load().bg_downsample1d_cubic(xc.data_ptr(), y.data_ptr(), S, L, C, _lib.stream()), "downsample")
     return _err(y.permute(0, 2, 1), want)

@@ -271,3 +271,23 @@ def test_autocast_selects_operand_dtype(pc):
 def test_vae_decode_fp16(pc, kind, n):
     e = pc.vae_case(kind, n, F16)
     assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])
+
+
+# ---- VAE encoders (training-time API surface) ------------------------------------------
+def test_downsample1d_cubic(pc):
+    assert pc.downsample1d_case()["max_abs"] < 1e-5
+    assert pc.downsample1d_case(S=2, L=32, C=128)["max_abs"] < 1e-5
+
+
+@pytest.mark.parametrize("kind,n", [("surf_enc", 2), ("edge_enc", 6)])
+def test_vae_encode_fp32(pc, kind, n):
+    e = pc.vae_case(kind, n, F32)
+    assert e["finite"] and e["max_abs"] < 2e-4 * max(1.0, e["ref_absmax"])
+
+
+@pytest.mark.parametrize("kind,n", [("surf_enc", 2), ("edge_enc", 6)])
+def test_vae_encode_16bit(pc, kind, n):
+    e = pc.vae_case(kind, n, BF16)
+    assert e["finite"] and e["max_abs"] < 0.15 * max(1.0, e["ref_absmax"])
+    e = pc.vae_case(kind, n, F16)
+    assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])

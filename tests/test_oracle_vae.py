@@ -45,3 +45,15 @@ def test_module_keys_match_checkpoint_layout():
     sd["encoder.conv_in.weight"] = torch.zeros(1)          # full-VAE checkpoints carry the encoder too (strict=False)
     r = m1.load_state_dict(sd, strict=False)
     assert not r.missing_keys and r.unexpected_keys == ["encoder.conv_in.weight"]
+
+
+def test_encoder_shapes_and_keys():
+    with torch.no_grad():
+        y = ov.surf_encode(ov.seeded_state_dict(ov.surf_encoder_spec(), 1), torch.zeros(2, 3, 32, 32))
+        assert y.shape == (2, 3, 4, 4)
+        y = ov.edge_encode(ov.seeded_state_dict(ov.edge_encoder_spec(), 2), torch.zeros(3, 3, 32))
+        assert y.shape == (3, 3, 4)
+    assert set(bga.AutoencoderKLFastEncode(**SURF_CFG).state_dict()) == set(ov.surf_encoder_spec())
+    assert set(bga.AutoencoderKL1DFastEncode(**EDGE_CFG).state_dict()) == set(ov.edge_encoder_spec())
+    # a constant signal stays constant under the cubic down-sampler (kernel sums to 1)
+    assert torch.allclose(ov.downsample1d_cubic(torch.ones(1, 1, 8)), torch.ones(1, 1, 4), atol=1e-6)
