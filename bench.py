@@ -46,13 +46,19 @@ def make_inputs(B, device, seed):
     return z.to(device), pos.to(device), mask.to(device)
 
 
+CPU_SAMPLE_B = 128     # bounded sample of the workload for the CPU leg: a quarter of the batch
+
+
 def cpu_baseline(steps=2, warmup=1):
     """The CPU oracle (a 'port': plain-math restatement of the reference, fp32, torch CPU threads) timed on a
-    bounded sample of the SAME workload: full batch 512 x 60 tokens, `steps` denoising steps after `warmup`."""
+    BOUNDED SAMPLE of the same workload: the first 128 of the 512 samples (60 tokens each), `steps` denoising steps
+    after `warmup`.  Every op of the path is per-sample, so a full 512-batch step costs 4x the sample's time; `value`
+    is reported in the bench's unit (steps/s at batch 512) with that factor applied."""
     from oracle import denoisers as orc
     from oracle.schedulers import OracleDDPM
     sd = orc.seeded_state_dict("SurfZNet", 0)
     z, pos, mask = make_inputs(B_PER_GPU, "cpu", 1234)
+    z, pos, mask = z[:CPU_SAMPLE_B], pos[:CPU_SAMPLE_B], mask[:CPU_SAMPLE_B]
     sch = OracleDDPM(clip_sample=True, clip_sample_range=3)
     sch.set_timesteps(1000)
     ts = sch.timesteps[-250:]
@@ -66,10 +72,23 @@ def cpu_baseline(steps=2, warmup=1):
             z = sch.step(eps, t, z, noise=torch.randn(z.shape, generator=g))
             if i >= warmup:
                 times.append(time.perf_counter() - t0)
-    per = sum(times) / len(times)
+    per = sum(times) / len(times) * (B_PER_GPU / CPU_SAMPLE_B)
     return {"value": round(1.0 / per, 4), "unit": "denoising-steps/s (batch=512)", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"full batch 512x60 tokens, {steps} timed steps after {warmup} warm-up, "
-            "oracle/denoisers.py + oracle/schedulers.py fp32 on torch CPU threads", "s_per_step": round(per, 3)}
+            "kind": "port", "sample": f"{CPU_SAMPLE_B} of the 512 samples x 60 tokens, {steps} timed steps after {warmup} "
+            f"warm-up (x{B_PER_GPU // CPU_SAMPLE_B} to a full batch: the path is per-sample), oracle/denoisers.py + "
+            "oracle/schedulers.py fp32 on torch CPU threads", "s_per_step_batch512": round(per, 3)}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_summary.py: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2
+    is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel.split("(")[0], {}).get("bytes_per_launch")
+    except OSError:
+        return None
 
 
 def main():
@@ -154,7 +173,7 @@ def main():
         dom = max(rows.values(), key=lambda r: r["total_ms"])
         ach = dom["flops"] / dom["total_ms"] / 1e9                    # TFLOP/s = flops per launch / avg duration
         roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"]}

@@ -33,8 +33,8 @@ struct ProfRec { hipEvent_t e0, e1; int kernel; double flops, bytes; };
 ProfRec* g_recs = nullptr;
 int g_cap = 0, g_n = 0;
 bool g_open = false;
-const char* const kProfNames[PK_COUNT] = {"gemm_bf16_p_kernel(128x128 persistent)", "gemm_bf16_128x64", "gemm_f32", "attn_bf16", "attn_f32",
-                                          "layernorm768", "cfg_ddpm_step", "pndm_step", "misc"};
+const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(128x64)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
+                                          "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {

@@ -373,7 +373,22 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        for (int kt = 0; kt < KT; ++kt) {
+        // residual / broadcast addend rows (fp32 epilogue): the first two MFMA tiles' worth (8 float4) are requested
+        // at the START of the last K-step, so their HBM / MALL latency hides behind that step's MFMAs
+        const int rbase = cm0 + wm * 64, cbase = cn0 + wn * 64;
+        float4 res[2][4];
+        auto load_res = [&](int t, int buf) {
+            const int i = t >> 1, j = t & 1;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int grow = rbase + i * 32 + it * 8 + (lane >> 3);
+                grow = grow < g.M ? grow : g.M - 1;
+                res[buf][it] = *reinterpret_cast<const float4*>(
+                    g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
+            }
+        };
+        auto kstep = [&](int kt, auto last_c) {
+            constexpr bool last = decltype(last_c)::value;
             unsigned long long ta = 0;
             if (INSTR) ta = __builtin_amdgcn_s_memtime();
             wait_vmcnt<0>();                                      // my pieces of this K-step (and older stores) done
@@ -381,11 +396,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
             __builtin_amdgcn_s_barrier();
             unsigned long long tb = 0;
             if (INSTR) { tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; }
-            if (kt + 1 < KT) {
+            if (!last) {
                 issue(slot ^ 1, (kt + 1) * G_BK);
-            } else if (has_next) {                                // keep the DMA stream running across the tile seam
-                set_tile(L + G, m0, n0);
-                issue(slot ^ 1, 0);
+            } else {
+                if (has_next) {                                   // keep the DMA stream running across the tile seam
+                    set_tile(L + G, m0, n0);
+                    issue(slot ^ 1, 0);
+                }
+                if (!half_fast && g.add) { load_res(0, 0); load_res(1, 1); }
             }
             const unsigned char* st = lds + slot * STAGE_BYTES;
             V8 af[2][TM], bf[2][TN];
@@ -415,12 +433,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 asm volatile("s_nop 0" ::: "memory");
                 t_comp += __builtin_amdgcn_s_memtime() - tb;
             }
-        }
+        };
+        for (int kt = 0; kt + 1 < KT; ++kt) kstep(kt, std::false_type{});
+        kstep(KT - 1, std::true_type{});
         unsigned long long te = 0;
         if (INSTR) te = __builtin_amdgcn_s_memtime();
 
         // ---------------- epilogue (wave-private patch; the ring already receives the next tile) ----------------
-        const int rbase = cm0 + wm * 64, cbase = cn0 + wn * 64;
         float bias_l[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bias_l[j] = g.bias ? g.bias[cbase + j * 32 + (lane & 31)] : 0.f;
@@ -461,20 +480,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
             }
         } else {
             float* pf = reinterpret_cast<float*>(patch);
-            // residual / broadcast addend: all 16 row-segment loads of this wave go out FIRST (64 VGPRs), so their
-            // HBM/MALL latency overlaps the patch traffic instead of forming 16 serial round trips
-            float4 res[2][4];                                     // two MFMA tiles of residual rows in flight
-            auto load_res = [&](int t, int buf) {
-                const int i = t >> 1, j = t & 1;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    int grow = rbase + i * 32 + it * 8 + (lane >> 3);
-                    grow = grow < g.M ? grow : g.M - 1;
-                    res[buf][it] = *reinterpret_cast<const float4*>(
-                        g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
-                }
-            };
-            if (g.add) { load_res(0, 0); load_res(1, 1); }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
