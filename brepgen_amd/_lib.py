@@ -68,6 +68,8 @@ _SIGNATURES = {
     "bg_downsample1d_cubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_upsample1d_cubic": (C.c_int, [fp, fp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_small_attn": (C.c_int, [fp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "bg_dedup_surfaces": (C.c_int, [fp, C.c_float, fp, u8p, C.c_int, C.c_int, vp]),
+    "bg_dedup_edges": (C.c_int, [fp, u8p, C.c_float, u8p, C.c_int, C.c_int, C.c_int, vp]),
     "bg_profile_begin": (C.c_int, [C.c_int]),
     "bg_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int]),
     "bg_tune_set": (C.c_int, [C.c_int, C.c_int]),

@@ -16,6 +16,8 @@ The VAE decode and the OpenCascade B-rep reconstruction that follow are outside 
 import numpy as np
 import torch
 
+from . import _lib
+from ._lib import check, ptr, stream
 from .utils import randn_tensor
 
 
@@ -67,9 +69,37 @@ def gather_latents(tensors, dist=None, group=None):
 
 
 # --------------------------------------------------------------------------------------------------
-# host de-duplication between the stages (numpy, as the reference; per sample -> shards with the batch)
+# de-duplication between the stages.  On the device (bg_dedup_*: no host sync inside the cascade) for CUDA tensors;
+# the numpy restatement of the reference's host loops is kept (`*_host`) as the checker of the device kernels.  Per sample -> shards with the batch.
 # --------------------------------------------------------------------------------------------------
 def dedup_surfaces(surfPos, threshold):
+    """sample.py:159-183.  surfPos [B,S,6] -> (surfPos padded with 0 [B,S,6], surfMask bool [B,S])."""
+    if not surfPos.is_cuda:
+        raise _lib.BrepgenHipError("dedup_surfaces runs on the MI355X (use dedup_surfaces_host for host tensors)")
+    B, S, _ = surfPos.shape
+    x = surfPos.detach().to(torch.float32).contiguous()
+    pos = torch.empty_like(x)
+    mask = torch.empty(B, S, dtype=torch.uint8, device=x.device)
+    check(_lib.load().bg_dedup_surfaces(ptr(x), float(np.float32(threshold)), ptr(pos), ptr(mask), B, S, stream()),
+          "bg_dedup_surfaces")
+    return pos, mask.view(torch.bool)
+
+
+def dedup_edges(edgePos, surfMask, threshold):
+    """sample.py:242-261.  -> edgeM bool [B,S,E], True = padded face or duplicate edge."""
+    if not edgePos.is_cuda:
+        raise _lib.BrepgenHipError("dedup_edges runs on the MI355X (use dedup_edges_host for host tensors)")
+    B, S, E, _ = edgePos.shape
+    x = edgePos.detach().to(torch.float32).contiguous()
+    sm = surfMask.contiguous()
+    sm = sm.view(torch.uint8) if sm.dtype == torch.bool else sm.to(torch.uint8)
+    em = torch.empty(B, S, E, dtype=torch.uint8, device=x.device)
+    check(_lib.load().bg_dedup_edges(ptr(x), ptr(sm), float(np.float32(threshold)), ptr(em), B, S, E, stream()),
+          "bg_dedup_edges")
+    return em.view(torch.bool)
+
+
+def dedup_surfaces_host(surfPos, threshold):
     """sample.py:159-183.  surfPos [B,S,6] (device) -> (surfPos padded with 0 [B,S,6], surfMask bool [B,S])."""
     B, S, _ = surfPos.shape
     host = np.round(surfPos.detach().float().cpu().numpy().reshape(B, S, 2, 3), 4)
@@ -89,7 +119,7 @@ def dedup_surfaces(surfPos, threshold):
     return torch.from_numpy(pos).to(surfPos.device), torch.from_numpy(mask).to(surfPos.device)
 
 
-def dedup_edges(edgePos, surfMask, threshold):
+def dedup_edges_host(edgePos, surfMask, threshold):
     """sample.py:242-261.  -> edgeM bool [B,S,E], True = padded face or duplicate edge."""
     B, S, E, _ = edgePos.shape
     host = edgePos.detach().float().cpu().numpy().reshape(B, S, E, 2, 3)

@@ -192,6 +192,15 @@ int bg_downsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stre
 int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype, int S, int T, int C, int nh, float scale,
                   bg_stream_t stream);
 
+/* ---- bbox de-duplication between the cascade stages, on the device (the reference does it on the host in numpy:
+ * sample.py:159-183 faces, 242-261 edges).  Same greedy order-dependent algorithm in float32, incl. the
+ * corner-swapped match and (faces) np.round(x, 4); decisions are bit-identical to the numpy code. */
+int bg_dedup_surfaces(const float* surf_pos /*[B,S,6]*/, float threshold, float* pos_out /*[B,S,6] kept, 0-padded*/,
+                      uint8_t* mask_out /*[B,S] 1 = padding*/, int B, int S, bg_stream_t stream);
+int bg_dedup_edges(const float* edge_pos /*[B,S,E,6]*/, const uint8_t* surf_mask /*[B,S]*/, float threshold,
+                   uint8_t* edge_mask /*[B,S,E] 1 = padded face or duplicate edge*/, int B, int S, int E,
+                   bg_stream_t stream);
+
 /* ---- measurement aid (bench.py's roofline leg): hipEvent pairs around every kernel launch ------------
  * bg_profile_begin allocates up to max_launches event pairs and switches recording on (this is the one
  * place the library owns state; it is off by default and costs nothing when off).  bg_profile_end

@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, thr=0.08):
     """Reference order of operations, CPU: sample.py:126-286 with the oracle in place of network.py/diffusers."""
-    from brepgen_amd.sampling import dedup_edges, dedup_surfaces
+    from brepgen_amd.sampling import dedup_edges_host as dedup_edges
+    from brepgen_amd.sampling import dedup_surfaces_host as dedup_surfaces
     from brepgen_amd.utils import randn_tensor
     from oracle import denoisers as orc
     from oracle.schedulers import OracleDDPM, OraclePNDM
@@ -88,3 +89,32 @@ def test_cascade_matches_oracle_cascade(use_cf):
         assert got[k].shape == want[k].shape, k
         d = float((got[k].cpu() - want[k]).abs().max())
         assert np.isfinite(d) and d < 5e-4, (k, d)     # fp32 path: per-step 1e-5 compounded over ~50 steps
+
+
+def test_device_dedup_is_bit_identical_to_the_numpy_loops():
+    """bg_dedup_surfaces / bg_dedup_edges vs the reference-order numpy code, incl. near-threshold and swapped boxes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from brepgen_amd.sampling import (dedup_edges, dedup_edges_host, dedup_surfaces, dedup_surfaces_host)
+    g = torch.Generator().manual_seed(4)
+    for B, S, E in [(5, 60, 30), (3, 100, 40), (2, 7, 3), (4, 64, 64)]:
+        base = torch.randn(B, 6, 6, generator=g).clamp(-3, 3)                     # 6 prototypes per sample
+        idx = torch.randint(0, 6, (B, S), generator=g)
+        pos = torch.gather(base, 1, idx.unsqueeze(-1).expand(B, S, 6)).clone()
+        jitter = (torch.rand(B, S, 6, generator=g) - 0.5) * 0.17                  # straddles the 0.08 threshold
+        pos = pos + jitter
+        swap = torch.rand(B, S, generator=g) < 0.3                                # corner-swapped duplicates
+        pos[swap] = torch.cat([pos[swap][:, 3:], pos[swap][:, :3]], dim=1)
+        hp, hm = dedup_surfaces_host(pos, 0.08)
+        dp, dm = dedup_surfaces(pos.cuda(), 0.08)
+        assert torch.equal(dm.cpu(), hm) and torch.equal(dp.cpu(), hp), (B, S)
+        ebase = torch.randn(B, S, 5, 6, generator=g).clamp(-3, 3)
+        eidx = torch.randint(0, 5, (B, S, E), generator=g)
+        ep = torch.gather(ebase, 2, eidx.unsqueeze(-1).expand(B, S, E, 6)) + (torch.rand(B, S, E, 6, generator=g) - 0.5) * 0.17
+        he = dedup_edges_host(ep, hm, 0.08)
+        de = dedup_edges(ep.cuda(), dm, 0.08)
+        assert torch.equal(de.cpu(), he), (B, S, E)
+        # a mask that is not left-aligned: the reference writes rows by position among the valid faces
+        odd = torch.zeros(B, S, dtype=torch.bool)
+        odd[:, ::3] = True
+        assert torch.equal(dedup_edges(ep.cuda(), odd.cuda(), 0.08).cpu(), dedup_edges_host(ep, odd, 0.08))
