@@ -291,3 +291,15 @@ def test_vae_encode_16bit(pc, kind, n):
     assert e["finite"] and e["max_abs"] < 0.15 * max(1.0, e["ref_absmax"])
     e = pc.vae_case(kind, n, F16)
     assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])
+
+
+def test_per_sample_timesteps_training_style(pc):
+    """timesteps of shape [B] (trainer.py:346-351 passes one t per sample) -> one time embedding per sample."""
+    from oracle import denoisers as orc
+    m, sd = pc.build_net("SurfZNet", 33, True, F32)
+    z, _, pos, mask, cl = pc.synth_inputs("SurfZNet", 4, 20, 1, True)
+    t = torch.tensor([3, 250, 999, 0])
+    with torch.no_grad():
+        want = orc.surfz_forward(sd, z, t, pos, mask, cl)
+        got = m(z.cuda(), t.cuda(), pos.cuda(), mask.cuda(), cl.cuda())
+    assert float((got.cpu() - want)[~mask].abs().max()) < 1e-5

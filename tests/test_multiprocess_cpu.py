@@ -46,7 +46,7 @@ def _worker(rank, world, port, B, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(420)
 def test_two_rank_gloo_run_equals_single_process():
     B, world = 8, 2
     ctx = mp.get_context("spawn")
@@ -55,9 +55,9 @@ def test_two_rank_gloo_run_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=90) for _ in range(world))
+    got = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
-        p.join(timeout=30)
+        p.join(timeout=60)
         assert p.exitcode == 0
     want = _single_process(B)
     for r in range(world):
