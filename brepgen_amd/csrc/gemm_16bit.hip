@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   fp32 output / residual: 32 x 32 fp32 slab per MFMA tile -> 128-byte row segments, residual added in flight.
 // ------------------------------------------------------------------------------------------------------
 template <bool F16, bool INSTR>
-__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int n_tiles, unsigned long long* dbg) {
+__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, unsigned long long* dbg) {
     using E = Elem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -301,8 +301,18 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int h = lane >> 5;
     const int nt_n = g.N_pad / BN;
     const int G = gridDim.x;
-    const int first = xcd_remap(blockIdx.x, G);                   // tiles first, first+G, ... : co-running workgroups
-    if (first >= n_tiles) return;                                 // of one XCD take consecutive tiles (shared A panel)
+    // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
+    // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
+    // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
+    // sub-grid column-fastest, so the ~64 concurrently running tiles of an XCD share ~7 A row panels and one W slice.
+    const int xcd = blockIdx.x & 7, w_local = blockIdx.x >> 3, cnt = G >> 3;      // G % 8 == 0 (launcher)
+    const int gx = xcd % ng, mg = xcd / ng, mgs = 8 / ng, ngt = nt_n / ng;
+    auto tile_at = [&](int t, int& tm0, int& tn0) -> bool {
+        const int panel = mg + (t / ngt) * mgs;
+        tm0 = panel * BM;
+        tn0 = (gx * ngt + t % ngt) * BN;
+        return panel < m_panels;
+    };
 
     // per-lane DMA source rows / swizzled chunks (tile independent part)
     int a_row[A_INSTR], a_chunk[A_INSTR], b_row[B_INSTR], b_chunk[B_INSTR];
@@ -318,9 +328,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     }
     const T* a_src[A_INSTR];
     const T* b_src[B_INSTR];
-    auto set_tile = [&](int L, int& m0, int& n0) {
-        m0 = (L / nt_n) * BM;
-        n0 = (L % nt_n) * BN;
+    auto set_src = [&](int m0, int n0) {
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             int grow = m0 + a_row[j];
@@ -359,12 +367,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     int m0, n0;
     unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0;
     if (INSTR) t_begin = __builtin_amdgcn_s_memtime();
-    set_tile(first, m0, n0);
+    if (!tile_at(w_local, m0, n0)) return;
+    set_src(m0, n0);
     issue(0, 0);
     int slot = 0;
-    for (int L = first; L < n_tiles; L += G) {
-        const bool has_next = L + G < n_tiles;
+    for (int t = w_local;; t += cnt) {
         const int cm0 = m0, cn0 = n0;                             // coordinates of the tile being computed
+        const bool has_next = tile_at(t + cnt, m0, n0);           // (m0, n0) now name the NEXT tile
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 issue(slot ^ 1, (kt + 1) * G_BK);
             } else {
                 if (has_next) {                                   // keep the DMA stream running across the tile seam
-                    set_tile(L + G, m0, n0);
+                    set_src(m0, n0);
                     issue(slot ^ 1, 0);
                 }
                 if (!half_fast && g.add) { load_res(0, 0); load_res(1, 1); }
@@ -519,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 }
         }
         if (INSTR) { t_epi += __builtin_amdgcn_s_memtime() - te; ++n_done; }
+        if (!has_next) break;
     }
     if (INSTR && dbg != nullptr && lane == 0) {
         unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -535,22 +545,28 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 64, 4, 1, 2>), dim3(m128 * (g.N_pad / 64)), dim3(256), 0, s, g);
         return launch_status("gemm16");
     }
+    const int nt = m128 * n128;
     const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
-                               (g.add2 == nullptr || g.ld_add2 % 4 == 0);
+                               (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64;
     const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
     if (variant == 10 || !persistent_ok) {                        // non-persistent 128x128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
+    } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
+        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g);
     } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g);
     } else {
-        const int nt = m128 * n128;
-        const int grid = nt < 512 ? nt : 512;                     // 2 resident workgroups per CU x 256 CUs
+        const int grid = nt < 512 ? (nt & ~7) : 512;              // 2 resident workgroups per CU x 256 CUs, multiple of 8
+        // column groups per launch (bg_tune_set key 4).  Measured on the QKV shape (W = 3.5 MB vs a 4 MB L2 per XCD):
+        // ng = 2 is not faster than ng = 1 once the clocks are warm, so 1 is shipped.
+        int ng = g_tune[4] > 0 ? g_tune[4] : 1;
+        if (n128 % ng != 0 || (ng != 1 && ng != 2 && ng != 4 && ng != 8)) ng = 1;
         if (variant == 31) {                                      // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, nt, dbg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, dbg);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, nt,
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng,
                                (unsigned long long*)nullptr);
         }
     }

@@ -58,6 +58,19 @@ def main():
             else:
                 d = float((o.float() - ref[name]).abs().max())
                 print(f"[check] variant {v} {name}: max|diff vs variant {VARIANTS[0]}| = {d:.3e}", flush=True)
+    if os.environ.get("NG"):
+        for name, (a, w, b, out, mode, N, K) in data.items():
+            line = f"[n-groups] {name:8s}:"
+            lib.bg_tune_set(0, 0)
+            for ng in [int(x) for x in os.environ["NG"].split(",")]:
+                lib.bg_tune_set(4, ng)
+                if mode == "bf16":
+                    us = timed(lambda: ops.linear(a, w, b, out=out, act=1 if name == "ffn1" else 0))
+                else:
+                    us = timed(lambda: ops.linear(a, w, b, add=out, out=out))
+                line += f"  ng{ng} {us:6.1f}us"
+            print(line, flush=True)
+        lib.bg_tune_set(4, 0)
     if os.environ.get("DEPHASE"):
         for name, (a, w, b, out, mode, N, K) in data.items():
             line = f"[dephase] {name:8s}:"
