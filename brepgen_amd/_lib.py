@@ -98,6 +98,9 @@ def load():
             fn.restype, fn.argtypes = res, args
         if lib.bg_abi_version() != 1:
             raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
+        for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):     # A/B knobs, e.g. BG_TUNE="0=10,5=1"
+            k, v = kv.split("=")
+            lib.bg_tune_set(int(k), int(v))
         _lib = lib
     return _lib
 

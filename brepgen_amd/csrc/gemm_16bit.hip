@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   fp32 output / residual: 32 x 32 fp32 slab per MFMA tile -> 128-byte row segments, residual added in flight.
 // ------------------------------------------------------------------------------------------------------
 template <bool F16, bool INSTR>
-__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, unsigned long long* dbg) {
+__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg) {
     using E = Elem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -307,7 +307,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     // sub-grid column-fastest, so the ~64 concurrently running tiles of an XCD share ~7 A row panels and one W slice.
     const int xcd = blockIdx.x & 7, w_local = blockIdx.x >> 3, cnt = G >> 3;      // G % 8 == 0 (launcher)
     const int gx = xcd % ng, mg = xcd / ng, mgs = 8 / ng, ngt = nt_n / ng;
+    const int first_l = xcd_remap(blockIdx.x, G);                 // walk 1: tiles first_l, first_l + G, ... in row-major order
     auto tile_at = [&](int t, int& tm0, int& tn0) -> bool {
+        if (walk == 1) {
+            const int L = first_l + ((t - w_local) / cnt) * G;
+            tm0 = (L / nt_n) * BM;
+            tn0 = (L % nt_n) * BN;
+            return L < m_panels * nt_n;
+        }
         const int panel = mg + (t / ngt) * mgs;
         tm0 = panel * BM;
         tn0 = (gx * ngt + t % ngt) * BN;
@@ -564,9 +571,9 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (variant == 31) {                                      // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, dbg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng,
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5],
                                (unsigned long long*)nullptr);
         }
     }
