@@ -25,7 +25,8 @@ class MlpWeights(C.Structure):
 class LayerWeights(C.Structure):
     _fields_ = [("ln1_g", fp), ("ln1_b", fp), ("ln2_g", fp), ("ln2_b", fp),
                 ("w_qkv", vp), ("b_qkv", fp), ("w_o", vp), ("b_o", fp),
-                ("w_1", vp), ("b_1", fp), ("w_2", vp), ("b_2", fp)]
+                ("w_1", vp), ("b_1", fp), ("w_2", vp), ("b_2", fp),
+                ("qkv_colsum", fp), ("w1_colsum", fp)]
 
 
 class DenoiserWeights(C.Structure):
@@ -44,6 +45,16 @@ class DenoiserInputs(C.Structure):
                 ("cond_cache_valid", C.c_int), ("_pad", C.c_int)]
 
 
+class GemmDesc(C.Structure):          # bg_gemm_desc
+    _fields_ = [("a", vp), ("lda", C.c_int), ("w", vp), ("bias", fp), ("out", vp), ("ldc", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("N_pad", C.c_int), ("K", C.c_int),
+                ("ab_dtype", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int),
+                ("add", fp), ("ld_add", C.c_int), ("add_div", C.c_int),
+                ("add2", fp), ("ld_add2", C.c_int), ("add2_div", C.c_int),
+                ("out_lo", vp), ("res_hi", vp), ("res_lo", vp), ("ld_res", C.c_int),
+                ("stats_out", fp), ("stats_in", fp), ("colsum", fp), ("ln_eps", C.c_float)]
+
+
 class ProfileRow(C.Structure):
     _fields_ = [("kernel", C.c_char_p), ("launches", C.c_int), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -56,6 +67,8 @@ _SIGNATURES = {
     "bg_layernorm_fwd": (C.c_int, [fp, fp, fp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp]),
     "bg_gemm_bias_act_fwd": (C.c_int, [vp, C.c_int, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, vp]),
+    "bg_gemm_ex_fwd": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_denoiser_fwd": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenoiserInputs), fp, vp, C.c_size_t, vp]),
@@ -96,7 +109,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export the ABI
             fn.restype, fn.argtypes = res, args
-        if lib.bg_abi_version() != 1:
+        if lib.bg_abi_version() != 2:
             raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
         for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):     # A/B knobs, e.g. BG_TUNE="0=10,5=1"
             k, v = kv.split("=")

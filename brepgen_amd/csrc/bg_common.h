@@ -95,13 +95,82 @@ struct GemmArgs {
     int act;                  // bg_act
     const float* add; int ld_add; int add_div;   // optional fp32 addend, row (m / add_div)
     const float* add2 = nullptr; int ld_add2 = 0; int add2_div = 1;   // optional second addend
+    // ---- 16-bit operands only: split residual stream + LayerNorm fold ----
+    // Split output: the fp32 result v is stored as two 16-bit planes hi = T(v) (-> out, ldc) and lo = T(v - hi)
+    // (-> out_lo, ldc); hi is directly the next GEMM's A operand, hi + lo carries ~16 mantissa bits of v.
+    void* out_lo = nullptr;
+    const void* res_hi = nullptr; const void* res_lo = nullptr; int ld_res = 0;   // split residual addend rows [M, N]
+    float* stats_out = nullptr;        // [N_pad/64][M][2] (part-major): per 64-column group (sum, sum of squares) of v
+    // LayerNorm fold on the consumer: a = 16-bit rows x (NOT normalised), w = T(gamma * W), bias = b + W beta,
+    // colsum[n] = sum_k w[n,k];  out = act(rstd_m * acc - mean_m * rstd_m * colsum[n] + bias[n]) with the row
+    // statistics summed from stats_in [K/64][M][2].
+    const float* stats_in = nullptr; const float* colsum = nullptr; float ln_eps = 1e-5f;
 };
+
+// 4 x 16-bit (bf16 | fp16) payload <-> floats
+template <bool F16> __device__ __forceinline__ void unpack4_16(uint2 u, float (&f)[4]) {
+    if (F16) {
+        union { uint2 u; half4_t h; } c; c.u = u;
+        f[0] = (float)c.h[0]; f[1] = (float)c.h[1]; f[2] = (float)c.h[2]; f[3] = (float)c.h[3];
+    } else {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+}
+// v -> (hi, lo) planes: hi = T(v), lo = T(v - float(hi)); (v - hi) is exact in fp32
+template <bool F16> __device__ __forceinline__ void split4_16(const float (&v)[4], uint2& hi, uint2& lo) {
+    hi = pack4_16(v[0], v[1], v[2], v[3], F16 ? BG_F16 : BG_BF16);
+    float h[4];
+    unpack4_16<F16>(hi, h);
+    lo = pack4_16(v[0] - h[0], v[1] - h[1], v[2] - h[2], v[3] - h[3], F16 ? BG_F16 : BG_BF16);
+}
+// butterfly sums inside aligned groups of 8 / 16 lanes (pure DPP, every lane ends with the group total; the
+// association order is fixed, so the persistent and the generic GEMM produce bit-identical row statistics)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror: lane i <- lane 7 - i of its 8-lane half row
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_mov<0x140>(v);     // row_mirror: lane i <- lane 15 - i of its 16-lane row
+    return v;
+}
+// Row statistics from the per-64-column partials a producer GEMM wrote.  The 16 (zero-padded) partials are summed
+// in the butterfly order of group16_sum, written out explicitly, so a lane that owns a whole row (persistent kernel)
+// and 16 lanes that share one (generic kernel) get bit-identical sums.
+__device__ __forceinline__ float tree16(const float (&p)[16]) {
+    const float q0 = (p[0] + p[1]) + (p[2] + p[3]), q1 = (p[4] + p[5]) + (p[6] + p[7]);
+    const float q2 = (p[8] + p[9]) + (p[10] + p[11]), q3 = (p[12] + p[13]) + (p[14] + p[15]);
+    return (q0 + q1) + (q2 + q3);
+}
+// (S, Q) = (sum, sum of squares) over K elements  ->  (rstd, -mean * rstd)
+__device__ __forceinline__ float2 ln_fold_coeffs(float S, float Q, int K, float eps) {
+    const float inv = 1.0f / (float)K;
+    const float mean = S * inv;
+    float var = Q * inv - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    return make_float2(rstd, -(mean * rstd));
+}
+// LayerNorm fold applied to one accumulator: rstd * acc + (-mean * rstd * colsum + bias')   (no fma contraction)
+__device__ __forceinline__ float ln_fold_apply(float acc, float rstd, float nmr, float colsum, float bias) {
+    const float t = nmr * colsum + bias;
+    return acc * rstd + t;
+}
 int gemm_f32(const GemmArgs& g, hipStream_t s);
 int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s);   // ab_dtype: BG_BF16 | BG_F16
 int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s);
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps,
                  int silu, hipStream_t s);
+// same, input rows given as the split pair x = hi + lo (16-bit planes of dtype y_dtype)
+int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
+                       float eps, hipStream_t s);
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s);
 int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
 // c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)

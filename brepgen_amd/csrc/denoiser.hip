@@ -60,7 +60,7 @@ __global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __re
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t off_x, off_h, off_r, off_small, off_f, off_mask, total;
+    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, total;
     int M, F;
 };
 
@@ -76,6 +76,7 @@ static Workspace plan(int net, int B, int S, int E, int dtype) {
     w.off_small = o; o += align_up((size_t)(4 * B + B) * 768 * 4);      // sincos, t0, t1(as fp32 worst case), temb, cvec
     w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
     w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
+    w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.M * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
     w.total = o;
     return w;
 }
@@ -89,11 +90,21 @@ struct Ctx {
     float* X;
     void* H;
     void* R;
+    // 16-bit compute dtypes with folded LayerNorms: the residual stream lives as two 16-bit planes x = XH + XL in the
+    // X region (same bytes as fp32), XH doubles as the A operand of the QKV / FFN1 GEMMs, and the producers of x
+    // (token embeds, out-proj, FFN2) leave per-row (sum, sum of squares) partials in `stats`.
+    bool fold = false;
+    void* XH = nullptr;
+    void* XL = nullptr;
+    float* stats = nullptr;
 };
 
 // Linear(k,768)+b -> LN -> SiLU -> Linear(768,n)+b (+adds) ; x fp32 rows (lda), or activations in compute dtype for fc_out
+// `to_stream`: the result goes to the token stream X -- fp32 rows (out = c.X, and add == c.X accumulates), or, in
+// fold mode, the split pair (XH, XL) with row statistics (accumulating = the stream is the addend)
 static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, int rows, float* out, int ldc,
-                     const float* add, int ld_add, int add_div, const float* add2, int ld_add2, int add2_div) {
+                     const float* add, int ld_add, int add_div, const float* add2, int ld_add2, int add2_div,
+                     bool to_stream = false) {
     float* t0 = reinterpret_cast<float*>(c.R);
     GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
     int rc = gemm(g1, m.w0_dtype, c.s);
@@ -103,6 +114,13 @@ static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, in
     GemmArgs g2{c.H, 768, m.w3, m.b3, out, ldc, rows, m.n_out, m.n_out_pad, 768, BG_F32, BG_ACT_NONE, add, ld_add,
                 add ? add_div : 1};
     g2.add2 = add2; g2.ld_add2 = ld_add2; g2.add2_div = add2 ? add2_div : 1;
+    if (to_stream && c.fold) {
+        g2.out = c.XH; g2.out_dtype = c.dtype; g2.out_lo = c.XL; g2.stats_out = c.stats;
+        if (add == c.X) {                                         // accumulate into the stream
+            g2.add = nullptr; g2.ld_add = 0; g2.add_div = 1;
+            g2.res_hi = c.XH; g2.res_lo = c.XL; g2.ld_res = 768;
+        }
+    }
     return gemm(g2, c.dtype, c.s);
 }
 
@@ -130,6 +148,15 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     c.H = c.ws + c.p.off_h;
     c.R = c.ws + c.p.off_r;
     const int M = c.p.M, F = c.p.F, N = S * E, nt = in->n_timesteps;
+    c.fold = w->dtype != BG_F32 && w->n_layer > 0 && w->layers[0].qkv_colsum != nullptr;
+    if (c.fold) {
+        for (int li = 0; li < w->n_layer; ++li)
+            BG_REQUIRE(w->layers[li].qkv_colsum && w->layers[li].w1_colsum, BG_E_ARG,
+                       "bg_denoiser_fwd: layer %d lacks the LayerNorm-fold column sums", li);
+        c.XH = c.X;
+        c.XL = reinterpret_cast<unsigned char*>(c.X) + (size_t)M * 768 * 2;
+        c.stats = reinterpret_cast<float*>(c.ws + c.p.off_stats);
+    }
     float* small = reinterpret_cast<float*>(c.ws + c.p.off_small);
     float* sc = small;                         // [nt,768] sincos
     float* temb = small + (size_t)3 * B * 768; // [nt,768]
@@ -157,18 +184,18 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
     switch (net) {
         case BG_SURFPOS:   // tokens = p_embed(x) + c
-            rc = embed_mlp(c, w->embed[0], in->x, 6, M, c.X, 768, cvec, 768, N, nullptr, 0, 1);
+            rc = embed_mlp(c, w->embed[0], in->x, 6, M, c.X, 768, cvec, 768, N, nullptr, 0, 1, true);
             break;
         case BG_SURFZ:     // tokens = z_embed(x) + p_embed(surfPos) + c
-            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1);
+            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1, true);
             break;
         case BG_EDGEPOS:   // tokens = edgep_embed(x) + surf[m/E] + c
-            rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E);
+            rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E, true);
             break;
         default:           // EdgeZ: edgez_embed(x[:, :12]) + vertp_fc(x[:, 12:]) + edgep_embed(edgePos) + surf[m/E] + c
-            rc = embed_mlp(c, w->embed[3], in->x, 18, M, c.X, 768, cvec, 768, N, fcond, 768, E);
-            if (!rc) rc = embed_mlp(c, w->embed[4], in->x + 12, 18, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1);
-            if (!rc) rc = embed_mlp(c, w->embed[2], in->edge_pos, 6, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1);
+            rc = embed_mlp(c, w->embed[3], in->x, 18, M, c.X, 768, cvec, 768, N, fcond, 768, E, true);
+            if (!rc) rc = embed_mlp(c, w->embed[4], in->x + 12, 18, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true);
+            if (!rc) rc = embed_mlp(c, w->embed[2], in->edge_pos, 6, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true);
             break;
     }
     if (rc) return rc;
@@ -185,7 +212,24 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
 
     // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
-    for (int li = 0; li < w->n_layer; ++li) {
+    for (int li = 0; c.fold && li < w->n_layer; ++li) {
+        // x = XH + XL.  LN1 / LN2 are folded: QKV and FFN1 read the raw 16-bit rows XH and normalise in their epilogue.
+        const bg_layer_weights& L = w->layers[li];
+        GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
+        if ((rc = gemm(qkv, c.dtype, s))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s))) return rc;
+        GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
+        if ((rc = gemm(op, c.dtype, s))) return rc;
+        GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
+        f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
+        if ((rc = gemm(f1, c.dtype, s))) return rc;
+        GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        f2.out_lo = c.XL; f2.res_hi = c.XH; f2.res_lo = c.XL; f2.ld_res = 768; f2.stats_out = c.stats;
+        if ((rc = gemm(f2, c.dtype, s))) return rc;
+    }
+    for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
         if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
@@ -204,7 +248,9 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // fc_out.0 reads the final-LN output from H and writes its fp32 result to R; the LN+SiLU then overwrites H.
     {
         void* hf = c.H;
-        if ((rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s))) return rc;
+        if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s);
+        else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s);
+        if (rc) return rc;
         const bg_mlp_weights& m = w->fc_out;
         rc = embed_mlp(c, m, hf, 768, M, eps_out, m.n_out, nullptr, 0, 1, nullptr, 0, 1);
     }

@@ -11,17 +11,30 @@ namespace bg {
 // Each lane owns 3 float4 (columns lane*4 + 256*j): fully coalesced 1 KiB per wave-load.
 // Two-pass statistics in registers (mean, then centred variance) == torch.nn.LayerNorm numerics.
 // ------------------------------------------------------------------------------------------------
-template <int OUT, bool SILU>    // OUT: BG_F32 | BG_F16 | BG_BF16
-__global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int OUT, bool SILU, bool SPLIT_IN = false>    // OUT: BG_F32 | BG_F16 | BG_BF16
+__global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x, const void* __restrict__ x_lo,
+                                                    const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, void* __restrict__ y, int M,
                                                     float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * 768);
     float4 v[3];
+    if (SPLIT_IN) {         // x = hi + lo, two 16-bit planes of dtype OUT (the denoisers' split residual stream)
+        const uint2* hr = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + (size_t)row * 768);
+        const uint2* lr = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x_lo) + (size_t)row * 768);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) v[j] = xr[lane + 64 * j];
+        for (int j = 0; j < 3; ++j) {
+            float fh[4], fl[4];
+            unpack4_16<OUT == BG_F16>(hr[lane + 64 * j], fh);
+            unpack4_16<OUT == BG_F16>(lr[lane + 64 * j], fl);
+            v[j] = make_float4(fh[0] + fl[0], fh[1] + fl[1], fh[2] + fl[2], fh[3] + fl[3]);
+        }
+    } else {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * 768);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] = xr[lane + 64 * j];
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 3; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -60,19 +73,34 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
     dim3 grid((M + 3) / 4), block(256);
     ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_F32 ? 4.0 : 2.0)), s);
     if (y_dtype == BG_BF16) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
     } else if (y_dtype == BG_F16) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F16, true>), grid, block, 0, s, x, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_F16, false>), grid, block, 0, s, x, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
     } else if (y_dtype == BG_F32) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F32, true>), grid, block, 0, s, x, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_F32, false>), grid, block, 0, s, x, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F32, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F32, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
     } else {
         set_error("layernorm: unsupported output dtype %d", y_dtype);
         return BG_E_DTYPE;
     }
     return launch_status("layernorm768");
+}
+
+int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
+                       float eps, hipStream_t s) {
+    if (M <= 0) return 0;
+    dim3 grid((M + 3) / 4), block(256);
+    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * 6.0, s);
+    const float* x = reinterpret_cast<const float*>(hi);
+    if (y_dtype == BG_BF16) hipLaunchKernelGGL((ln768_kernel<BG_BF16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps);
+    else if (y_dtype == BG_F16) hipLaunchKernelGGL((ln768_kernel<BG_F16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps);
+    else {
+        set_error("layernorm (split input): unsupported dtype %d", y_dtype);
+        return BG_E_DTYPE;
+    }
+    return launch_status("layernorm768_split");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +298,12 @@ extern "C" int bg_layernorm_fwd(const float* x, const float* gamma, const float*
     BG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
                    ((uintptr_t)beta & 15) == 0, BG_E_ALIGN, "bg_layernorm_fwd: pointers must be 16-byte aligned");
     return bg::layernorm768(x, gamma, beta, y, y_dtype, M, eps, fuse_silu, (hipStream_t)stream);
+}
+
+extern "C" int bg_layernorm_split_fwd(const void* hi, const void* lo, const float* gamma, const float* beta, void* y,
+                                      int dtype, int M, float eps, bg_stream_t stream) {
+    BG_REQUIRE(hi && lo && gamma && beta && y, BG_E_ARG, "bg_layernorm_split_fwd: null pointer");
+    return bg::layernorm768_split(hi, lo, gamma, beta, y, dtype, M, eps, (hipStream_t)stream);
 }
 
 extern "C" int bg_cfg_ddpm_step(const float* eps_c, const float* eps_u, float guidance_w, const float* x,

@@ -222,37 +222,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 
     constexpr int LPR = PW / 4;                                   // lanes per patch row (float4 each)
     constexpr int RPI = 64 / LPR;                                 // rows per iteration
+    static_assert(PW == 64, "the row-statistics / LayerNorm-fold code assumes one 64-column group per wave");
     const int rr = lane / LPR, c4 = (lane % LPR) * 4;
     const int gcol = n0 + wn * PW + c4;
     const bool vec = (g.N == g.N_pad) && ((g.ldc & 3) == 0) && (g.add == nullptr || (g.ld_add & 3) == 0) &&
                      (g.add2 == nullptr || (g.ld_add2 & 3) == 0);
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), csum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) bias = *reinterpret_cast<const float4*>(g.bias + gcol);
+    if (g.stats_in) csum = *reinterpret_cast<const float4*>(g.colsum + gcol);
+    const int nparts_in = g.K / G_BK;
 #pragma unroll 4
     for (int it = 0; it < TM * 32 / RPI; ++it) {
         const int pr = it * RPI + rr;
         const int grow = m0 + wm * (TM * 32) + pr;
-        if (grow >= g.M) continue;
+        const bool row_ok = grow < g.M;
+        const int crow = row_ok ? grow : g.M - 1;
         float4 v = *reinterpret_cast<const float4*>(&patch[pr * PW + c4]);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (g.stats_in) {                                         // LayerNorm fold: the 16 lanes of a row share its statistics
+            float2 pq = make_float2(0.f, 0.f);
+            if (lane % LPR < nparts_in)
+                pq = *reinterpret_cast<const float2*>(g.stats_in + ((size_t)(lane % LPR) * g.M + crow) * 2);
+            const float2 cf = ln_fold_coeffs(group16_sum(pq.x), group16_sum(pq.y), g.K, g.ln_eps);
+            v.x = ln_fold_apply(v.x, cf.x, cf.y, csum.x, bias.x);
+            v.y = ln_fold_apply(v.y, cf.x, cf.y, csum.y, bias.y);
+            v.z = ln_fold_apply(v.z, cf.x, cf.y, csum.z, bias.z);
+            v.w = ln_fold_apply(v.w, cf.x, cf.y, csum.w, bias.w);
+        } else {
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        }
         if (g.act == BG_ACT_RELU) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (vec) {
             if (g.add) {
-                const float4 a4 = *reinterpret_cast<const float4*>(g.add + (size_t)(grow / g.add_div) * g.ld_add + gcol);
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add + (size_t)(crow / g.add_div) * g.ld_add + gcol);
                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+            }
+            if (g.res_hi) {                                       // split residual stream: x_old = hi + lo
+                const size_t o = (size_t)crow * g.ld_res + gcol;
+                float fh[4], fl[4];
+                unpack4_16<F16>(*reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(g.res_hi) + o), fh);
+                unpack4_16<F16>(*reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(g.res_lo) + o), fl);
+                v.x += fh[0] + fl[0]; v.y += fh[1] + fl[1]; v.z += fh[2] + fl[2]; v.w += fh[3] + fl[3];
             }
             if (g.add2) {
-                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(grow / g.add2_div) * g.ld_add2 + gcol);
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol);
                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
             }
-            if (g.out_dtype != BG_F32)
+            if (g.stats_out) {                                    // per-64-column (sum, sum of squares) of the fp32 result
+                const float s4 = (v.x + v.y) + (v.z + v.w);
+                const float q4 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                const float S = group16_sum(s4), Q = group16_sum(q4);
+                if (row_ok && lane % LPR == 0)
+                    *reinterpret_cast<float2*>(g.stats_out + ((size_t)((n0 + wn * PW) / 64) * g.M + grow) * 2) =
+                        make_float2(S, Q);
+            }
+            if (!row_ok) continue;
+            if (g.out_lo) {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+                uint2 hi, lo;
+                split4_16<F16>(vv, hi, lo);
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) = hi;
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out_lo) + (size_t)grow * g.ldc + gcol) = lo;
+            } else if (g.out_dtype != BG_F32)
                 *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
                     E::pack4(v.x, v.y, v.z, v.w);
             else
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
         } else {
+            if (!row_ok) continue;
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -281,8 +319,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   32 x 64 bf16 slab (128-byte rows) -> 16-byte-per-lane, full-line global stores.
 //   fp32 output / residual: 32 x 32 fp32 slab per MFMA tile -> 128-byte row segments, residual added in flight.
 // ------------------------------------------------------------------------------------------------------
-template <bool F16, bool INSTR>
+// MODE selects the epilogue (one instantiation each, so that no instantiation carries the registers of another):
+//   P_PLAIN16  16-bit output, bias (+ReLU)                              -- QKV / FFN1 without the LayerNorm fold, VAE convs
+//   P_FOLD16   same with the LayerNorm fold (stats_in / colsum)         -- QKV / FFN1 of the denoisers
+//   P_GENERAL  fp32 or 16-bit output with fp32 addends (add / add2)     -- fp32 residual stream, embeds, VAE residuals
+//   P_SPLIT    split (hi, lo) output, addend = split residual or fp32 broadcast rows, optional row statistics
+//                                                                       -- out-proj / FFN2 / token embeds of the denoisers
+enum { P_PLAIN16 = 0, P_FOLD16 = 1, P_GENERAL = 2, P_SPLIT = 3 };
+constexpr int FOLD_PARTS = 12;      // the persistent kernel's LayerNorm fold is compiled for K = 768 (LN width of the denoisers)
+
+template <bool F16, int MODE, bool INSTR>
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg) {
+    constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     using E = Elem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -368,7 +416,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     }
 
     unsigned* patch = reinterpret_cast<unsigned*>(lds + RING + wave * 4096);
-    const bool half_fast = g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr;
+    constexpr bool half_fast = FAST;
+    const bool has_res = !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
     const int KT = g.K / G_BK;
 
     int m0, n0;
@@ -392,8 +441,26 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         // residual / broadcast addend rows (fp32 epilogue): the first two MFMA tiles' worth (8 float4) are requested
         // at the START of the last K-step, so their HBM / MALL latency hides behind that step's MFMAs
         const int rbase = cm0 + wm * 64, cbase = cn0 + wn * 64;
+        // (P_SPLIT works on 16-row x 64-column slabs, slab t = i * 2 + half, 8 columns per lane: res[buf][2 * it],
+        //  res[buf][2 * it + 1] hold either the (hi, lo) octets of the split residual or 8 fp32 addend values)
         float4 res[2][4];
         auto load_res = [&](int t, int buf) {
+            if (SPLIT) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    int grow = rbase + t * 16 + it * 8 + (lane >> 3);
+                    grow = grow < g.M ? grow : g.M - 1;
+                    // two 16-byte loads either way (hi / lo octets, or 8 fp32 addends): select the ADDRESSES, so the
+                    // loads themselves stay unconditional and in flight together
+                    const size_t o = (size_t)grow * g.ld_res + cbase + (lane & 7) * 8;
+                    const float* ap = g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
+                    const void* p0 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_hi) + o) : (const void*)ap;
+                    const void* p1 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_lo) + o) : (const void*)(ap + 4);
+                    res[buf][2 * it] = *reinterpret_cast<const float4*>(p0);
+                    res[buf][2 * it + 1] = *reinterpret_cast<const float4*>(p1);
+                }
+                return;
+            }
             const int i = t >> 1, j = t & 1;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -402,6 +469,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 res[buf][it] = *reinterpret_cast<const float4*>(
                     g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
             }
+        };
+        // LayerNorm fold (consumer): lane l owns the statistics of row rbase + l; its <= 16 partial pairs are requested
+        // at the start of the last K-step as well
+        float2 st[16];
+        auto load_stats = [&]() {
+            int grow = rbase + lane;
+            grow = grow < g.M ? grow : g.M - 1;
+            const float2* sp = reinterpret_cast<const float2*>(g.stats_in) + grow;     // part-major: [KT][M] pairs
+#pragma unroll
+            for (int p = 0; p < 16; ++p)                          // K == 768 (launcher): 12 unconditional loads in flight together
+                st[p] = p < FOLD_PARTS ? sp[(size_t)p * g.M] : make_float2(0.f, 0.f);
         };
         auto kstep = [&](int kt, auto last_c) {
             constexpr bool last = decltype(last_c)::value;
@@ -419,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     set_src(m0, n0);
                     issue(slot ^ 1, 0);
                 }
-                if (!half_fast && g.add) { load_res(0, 0); load_res(1, 1); }
+                if (!FAST && has_res) { load_res(0, 0); load_res(1, 1); }
+                if (FOLD) load_stats();
             }
             const unsigned char* st = lds + slot * STAGE_BYTES;
             V8 af[2][TM], bf[2][TN];
@@ -461,13 +540,39 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         for (int j = 0; j < TN; ++j) bias_l[j] = g.bias ? g.bias[cbase + j * 32 + (lane & 31)] : 0.f;
         if (half_fast) {
             T* out = reinterpret_cast<T*>(g.out);
+            constexpr bool fold = FOLD;
+            float2 cf = make_float2(1.f, 0.f);                    // (rstd, -mean * rstd) of row rbase + lane
+            float cs_l[TN] = {0.f, 0.f};
+            if (fold) {
+                float ps[16], pq[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) { ps[p] = st[p].x; pq[p] = st[p].y; }
+                cf = ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) cs_l[j] = g.colsum[cbase + j * 32 + (lane & 31)];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                float cA[16], cB[16];                             // coefficients of this lane's 16 accumulator rows
+                if (fold) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int src = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        cA[r] = __shfl(cf.x, src, 64);
+                        cB[r] = __shfl(cf.y, src, 64);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int rp = 0; rp < 8; ++rp) {
-                        float a = acc[i][j][2 * rp] + bias_l[j], b = acc[i][j][2 * rp + 1] + bias_l[j];
+                        float a, b;
+                        if (fold) {
+                            a = ln_fold_apply(acc[i][j][2 * rp], cA[2 * rp], cB[2 * rp], cs_l[j], bias_l[j]);
+                            b = ln_fold_apply(acc[i][j][2 * rp + 1], cA[2 * rp + 1], cB[2 * rp + 1], cs_l[j], bias_l[j]);
+                        } else {
+                            a = acc[i][j][2 * rp] + bias_l[j]; b = acc[i][j][2 * rp + 1] + bias_l[j];
+                        }
                         if (g.act == BG_ACT_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
                         // even lane keeps row r (cols c, c+1), odd lane row r+1 (cols c-1, c)
                         const float send = (lane & 1) ? a : b;
@@ -494,6 +599,83 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
+        } else if (SPLIT) {
+            // split residual stream: slabs of 16 rows x 64 columns (accumulator registers 8*half .. 8*half+7 of both
+            // column blocks) go through the 4 KiB patch; on the way back every lane owns 8 consecutive columns of a
+            // row, so hi and lo leave as 16-byte stores of 128-byte row segments, the residual arrives the same way,
+            // and one 8-lane butterfly yields the row's (sum, sum of squares) over this wave's 64 columns.
+            float* pf = reinterpret_cast<float*>(patch);
+            float2 row_sq = make_float2(0.f, 0.f);               // (sum, sum of squares) of wave-tile row `lane`
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = t >> 1, half = t & 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        float v = acc[i][j][half * 8 + rr] + bias_l[j];
+                        if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+                        pf[((rr & 3) + 8 * (rr >> 2) + 4 * h) * 64 + j * 32 + (lane & 31)] = v;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int prow = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                    const float4 p0 = *reinterpret_cast<const float4*>(&pf[prow * 64 + c8]);
+                    const float4 p1 = *reinterpret_cast<const float4*>(&pf[prow * 64 + c8 + 4]);
+                    float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                    const int grow = rbase + t * 16 + prow, gcol = cbase + c8;
+                    const bool row_ok = grow < g.M;
+                    if (has_res) {
+                        const float4 r0 = res[t & 1][2 * it], r1 = res[t & 1][2 * it + 1];
+                        if (g.res_hi) {                           // x_old = hi + lo
+                            float fh[4], fl[4];
+                            unpack4_16<F16>(make_uint2(__float_as_uint(r0.x), __float_as_uint(r0.y)), fh);
+                            unpack4_16<F16>(make_uint2(__float_as_uint(r1.x), __float_as_uint(r1.y)), fl);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += fh[e] + fl[e];
+                            unpack4_16<F16>(make_uint2(__float_as_uint(r0.z), __float_as_uint(r0.w)), fh);
+                            unpack4_16<F16>(make_uint2(__float_as_uint(r1.z), __float_as_uint(r1.w)), fl);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 + e] += fh[e] + fl[e];
+                        } else {
+                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                        }
+                    }
+                    if (g.add2) {
+                        const int crow = row_ok ? grow : g.M - 1;
+                        const float* ap = g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol;
+                        const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
+                        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
+                        v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+                    }
+                    if (g.stats_out) {
+                        // same association order as the generic kernel: 4-column chunk partials, then a butterfly
+                        const float s8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                        const float q8 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
+                                         ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                        const float S = group8_sum(s8), Q = group8_sum(q8);
+                        // row t*16 + it*8 + (lane >> 3) is complete in its 8 lanes; hand it to lane == row
+                        const float Sx = __shfl(S, (lane & 7) * 8, 64), Qx = __shfl(Q, (lane & 7) * 8, 64);
+                        if ((lane >> 3) == t * 2 + it) row_sq = make_float2(Sx, Qx);
+                    }
+                    if (row_ok) {
+                        const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+                        uint2 ha, la, hb, lb;
+                        split4_16<F16>(va, ha, la);
+                        split4_16<F16>(vb, hb, lb);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(g.out_lo) + (size_t)grow * g.ldc + gcol) = make_uint4(la.x, la.y, lb.x, lb.y);
+                    }
+                }
+                if (has_res && t + 2 < 4) load_res(t + 2, t & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (g.stats_out && rbase + lane < g.M)               // part-major [N/64][M] pairs: one 512-byte store per wave
+                reinterpret_cast<float2*>(g.stats_out)[(size_t)(cbase / 64) * g.M + rbase + lane] = row_sq;
         } else {
             float* pf = reinterpret_cast<float*>(patch);
 #pragma unroll
@@ -513,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                         const int prow = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
                         float4 v = *reinterpret_cast<const float4*>(&pf[prow * 32 + c4]);
                         const int grow = rbase + i * 32 + prow, gcol = cbase + j * 32 + c4;
-                        if (g.add) {
+                        if (has_res) {
                             const float4 a4 = res[(i * TN + j) & 1][it];
                             v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
                         }
@@ -529,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
                         }
                     }
-                    if (g.add && i * TN + j + 2 < TM * TN) load_res(i * TN + j + 2, (i * TN + j) & 1);
+                    if (has_res && i * TN + j + 2 < TM * TN) load_res(i * TN + j + 2, (i * TN + j) & 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -555,8 +737,10 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     const int nt = m128 * n128;
     const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
                                (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64;
+    // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
+    //  persistent and the generic kernel implement them, with bit-identical arithmetic)
     const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
-    if (variant == 10 || !persistent_ok) {                        // non-persistent 128x128, 2-stage ring
+    if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
     } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g);
@@ -568,13 +752,21 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         // ng = 2 is not faster than ng = 1 once the clocks are warm, so 1 is shipped.
         int ng = g_tune[4] > 0 ? g_tune[4] : 1;
         if (n128 % ng != 0 || (ng != 1 && ng != 2 && ng != 4 && ng != 8)) ng = 1;
-        if (variant == 31) {                                      // s_memtime phase accounting (tools/gemm_instr.py)
+        const bool fast = g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.out_lo == nullptr;
+        unsigned long long* none = nullptr;
+        if (variant == 31 && g.out_lo == nullptr && g.stats_in == nullptr) {   // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
+            if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
+            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
+        } else if (g.out_lo) {
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+        } else if (g.stats_in) {
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+        } else if (fast) {
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5],
-                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
         }
     }
     return launch_status("gemm16");
@@ -594,6 +786,18 @@ int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s) {
     if (g.out_dtype != BG_F32 && g.out_dtype != ab_dtype) {
         set_error("gemm_16bit: a 16-bit output must have the operand dtype (out %d, operands %d)", g.out_dtype, ab_dtype);
         return BG_E_DTYPE;
+    }
+    if (g.stats_in || g.out_lo || g.res_hi || g.stats_out) {
+        const bool ok_common = g.N == g.N_pad && g.ldc % 8 == 0;
+        const bool ok_fold = g.stats_in == nullptr || (g.colsum && g.bias && g.K / G_BK <= 16 && g.out_dtype == ab_dtype &&
+                                                       !g.add && !g.add2 && !g.out_lo && !g.res_hi && !g.stats_out);
+        const bool ok_split = g.out_lo == nullptr || g.out_dtype == ab_dtype;
+        const bool ok_res = g.res_hi == nullptr || (g.res_lo && g.out_lo && !g.add && !g.add2 && g.ld_res % 8 == 0);
+        const bool ok_stats = g.stats_out == nullptr || g.out_lo != nullptr;
+        if (!(ok_common && ok_fold && ok_split && ok_res && ok_stats)) {
+            set_error("gemm_16bit: invalid split-residual / LayerNorm-fold argument combination");
+            return BG_E_ARG;
+        }
     }
     // algorithmic cost: 2*M*N*K flops; bytes = operands once + output once (+ addends)
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;

@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return 0;
+    if (g.out_lo || g.res_hi || g.stats_out || g.stats_in) {
+        set_error("gemm_f32: split residual / LayerNorm fold exist for 16-bit operands only");
+        return BG_E_DTYPE;
+    }
     const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
     ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K,
@@ -90,6 +94,21 @@ int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s) {
 }
 
 }  // namespace bg
+
+extern "C" int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream) {
+    BG_REQUIRE(d && d->a && d->w && d->out, BG_E_ARG, "bg_gemm_ex_fwd: null pointer");
+    BG_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0 && d->N_pad >= d->N && d->lda >= d->K && d->ldc >= d->N, BG_E_SHAPE,
+               "bg_gemm_ex_fwd: bad shape M=%d N=%d N_pad=%d K=%d lda=%d ldc=%d", d->M, d->N, d->N_pad, d->K, d->lda, d->ldc);
+    BG_REQUIRE(d->out_dtype == BG_F32 || d->out_dtype == BG_BF16 || d->out_dtype == BG_F16, BG_E_DTYPE, "bg_gemm_ex_fwd: out dtype %d", d->out_dtype);
+    BG_REQUIRE((d->add == nullptr || d->add_div >= 1) && (d->add2 == nullptr || d->add2_div >= 1), BG_E_ARG,
+               "bg_gemm_ex_fwd: addend divisors must be >= 1");
+    bg::GemmArgs g{d->a, d->lda, d->w, d->bias, d->out, d->ldc, d->M, d->N, d->N_pad, d->K, d->out_dtype, d->act,
+                   d->add, d->ld_add, d->add ? d->add_div : 1};
+    g.add2 = d->add2; g.ld_add2 = d->ld_add2; g.add2_div = d->add2 ? d->add2_div : 1;
+    g.out_lo = d->out_lo; g.res_hi = d->res_hi; g.res_lo = d->res_lo; g.ld_res = d->ld_res;
+    g.stats_out = d->stats_out; g.stats_in = d->stats_in; g.colsum = d->colsum; g.ln_eps = d->ln_eps;
+    return bg::gemm(g, d->ab_dtype, (hipStream_t)stream);
+}
 
 extern "C" int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const float* bias, void* out, int ldc,
                                     int M, int N, int N_pad, int K, int ab_dtype, int out_dtype, int act,

@@ -76,6 +76,7 @@ class _HipDenoiser(nn.Module):
         self.net = _EncoderParams()
         self.compute_dtype = None        # None: follow autocast (bf16 inside, fp32 outside)
         self.cache_conditioning = True   # reuse step-invariant conditioning embeds while the inputs are unchanged
+        self.fold_layernorm = True       # 16-bit dtypes: norm1 / norm2 folded into the QKV / FFN1 GEMMs, split residual
         self._packs = {}
         self._workspace = None
         self._cond = None                # conditioning-embed cache entry
@@ -94,8 +95,9 @@ class _HipDenoiser(nn.Module):
         self._packs, self._cond = {}, None
 
     def _pack(self, dt):
-        if dt in self._packs:
-            return self._packs[dt]
+        fold = bool(self.fold_layernorm) and dt != torch.float32
+        if (dt, fold) in self._packs:
+            return self._packs[(dt, fold)]
         keep = []                                        # owns every packed tensor the descriptor points to
         code = {torch.bfloat16: BG_BF16, torch.float16: BG_F16, torch.float32: BG_F32}[dt]
 
@@ -104,11 +106,13 @@ class _HipDenoiser(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        def mat(p, scale_rows=0, pad_to=1):
+        def mat(p, scale_rows=0, pad_to=1, gamma=None):
             t = p.detach().to(torch.float32)
             if scale_rows:                               # fold the 1/sqrt(64) softmax scale into the q rows (exact)
                 t = t.clone()
                 t[:scale_rows] *= 0.125
+            if gamma is not None:                        # LayerNorm fold: W' = W * gamma (per input column)
+                t = t * gamma.detach().to(torch.float32)[None, :]
             if t.shape[0] % pad_to:
                 t = torch.cat([t, t.new_zeros((-t.shape[0]) % pad_to, *t.shape[1:])])
             t = t.to(dt).contiguous()
@@ -138,12 +142,26 @@ class _HipDenoiser(nn.Module):
             L = w.layers[i]
             L.ln1_g, L.ln1_b = f32(layer.norm1.weight), f32(layer.norm1.bias)
             L.ln2_g, L.ln2_b = f32(layer.norm2.weight), f32(layer.norm2.bias)
-            L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D)
             bq = layer.self_attn.in_proj_bias.detach().to(torch.float32).clone()
             bq[:D] *= 0.125
-            L.b_qkv = f32(bq)
+            if fold:
+                # LN(x) W^T + b = rstd * (x (gamma*W)^T) - mean * rstd * colsum(gamma*W) + (b + W beta): the GEMM reads
+                # the raw 16-bit residual rows and applies the row statistics in its epilogue (csrc/gemm_16bit.hip)
+                wq = layer.self_attn.in_proj_weight.detach().to(torch.float32).clone()
+                wq[:D] *= 0.125
+                L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D, gamma=layer.norm1.weight)
+                L.qkv_colsum = f32(keep[-1].to(torch.float32).sum(1))
+                L.b_qkv = f32(bq + wq @ layer.norm1.bias.detach().to(torch.float32))
+                w1 = layer.linear1.weight.detach().to(torch.float32)
+                L.w_1 = mat(layer.linear1.weight, gamma=layer.norm2.weight)
+                L.w1_colsum = f32(keep[-1].to(torch.float32).sum(1))
+                L.b_1 = f32(layer.linear1.bias.detach().to(torch.float32) + w1 @ layer.norm2.bias.detach().to(torch.float32))
+            else:
+                L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D)
+                L.b_qkv = f32(bq)
+                L.w_1, L.b_1 = mat(layer.linear1.weight), f32(layer.linear1.bias)
+                L.qkv_colsum = L.w1_colsum = None
             L.w_o, L.b_o = mat(layer.self_attn.out_proj.weight), f32(layer.self_attn.out_proj.bias)
-            L.w_1, L.b_1 = mat(layer.linear1.weight), f32(layer.linear1.bias)
             L.w_2, L.b_2 = mat(layer.linear2.weight), f32(layer.linear2.bias)
         w.lnf_g, w.lnf_b = f32(self.net.norm.weight), f32(self.net.norm.bias)
         w.time_embed = mlp(self.time_embed)
@@ -151,8 +169,8 @@ class _HipDenoiser(nn.Module):
         for i, name in enumerate(self.EMBEDS):
             w.embed[i] = mlp(getattr(self, name))
         w.class_embed = f32(self.class_embed.embed.weight) if self.use_cf else None
-        self._packs[dt] = (w, keep)
-        return self._packs[dt]
+        self._packs[(dt, fold)] = (w, keep)
+        return self._packs[(dt, fold)]
 
     # ---- helpers ----------------------------------------------------------------------------------
     def _dtype(self):

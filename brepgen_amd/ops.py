@@ -61,6 +61,53 @@ def linear(a, w, bias=None, out_dtype=torch.float32, act=BG_ACT_NONE, add=None, 
     return out
 
 
+def linear_ex(a, w, bias=None, *, act=BG_ACT_NONE, out_dtype=None, add=None, add_div=1, add2=None, add2_div=1,
+              split_out=False, res=None, want_stats=False, stats_in=None, colsum=None, ln_eps=1e-5):
+    """bg_gemm_ex_fwd.  Returns a dict: out (or hi), lo (split_out), stats (want_stats: [N/64, M, 2]).
+
+    res = (hi, lo) split residual rows added to the result; stats_in/colsum = LayerNorm fold on the A rows."""
+    _need_cuda(a, w, bias, add, add2, stats_in, colsum)
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1]
+    a, w = a.contiguous(), w.contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    odt = a.dtype if (split_out or out_dtype is None) else out_dtype
+    out = torch.empty(M, N, device=a.device, dtype=odt)
+    d = _lib.GemmDesc()
+    d.a, d.lda, d.w, d.bias, d.out, d.ldc = ptr(a), K, ptr(w), ptr(bias), ptr(out), N
+    d.M, d.N, d.N_pad, d.K = M, N, N, K
+    d.ab_dtype, d.out_dtype, d.act = bg_dtype(a.dtype), bg_dtype(odt), act
+    d.add, d.ld_add, d.add_div = ptr(add), (add.shape[-1] if add is not None else 0), add_div
+    d.add2, d.ld_add2, d.add2_div = ptr(add2), (add2.shape[-1] if add2 is not None else 0), add2_div
+    r = {"out": out}
+    if split_out:
+        r["lo"] = torch.empty_like(out)
+        d.out_lo = ptr(r["lo"])
+    if res is not None:
+        d.res_hi, d.res_lo, d.ld_res = ptr(res[0]), ptr(res[1]), res[0].shape[-1]
+    if want_stats:
+        r["stats"] = torch.zeros(N // 64, M, 2, device=a.device, dtype=torch.float32)
+        d.stats_out = ptr(r["stats"])
+    if stats_in is not None:
+        d.stats_in, d.colsum = ptr(stats_in.contiguous()), ptr(colsum.contiguous())
+    d.ln_eps = ln_eps
+    r["_keep"] = (a, w, bias, add, add2, res, stats_in, colsum)
+    check(_lib.load().bg_gemm_ex_fwd(d, stream()), "bg_gemm_ex_fwd")
+    return r
+
+
+def layernorm_split(hi, lo, gamma, beta, eps=1e-5):
+    """LayerNorm(768) of x = hi + lo (two 16-bit planes) -> same 16-bit dtype."""
+    _need_cuda(hi, lo, gamma, beta)
+    assert hi.dtype == lo.dtype and hi.shape == lo.shape and hi.shape[-1] == 768
+    hi, lo = hi.contiguous(), lo.contiguous()
+    y = torch.empty_like(hi)
+    check(_lib.load().bg_layernorm_split_fwd(ptr(hi), ptr(lo), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(y),
+                                             bg_dtype(hi.dtype), hi.numel() // 768, eps, stream()),
+          "bg_layernorm_split_fwd")
+    return y
+
+
 def attention(qkv, key_pad, B, N):
     """qkv [B*N, 2304] (q pre-scaled by 1/8), key_pad bool/uint8 [B,N] or None -> [B*N, 768]."""
     _need_cuda(qkv, key_pad)

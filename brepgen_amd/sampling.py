@@ -145,6 +145,20 @@ def dedup_edges_host(edgePos, surfMask, threshold):
 
 
 # --------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def decode_latents(surf_vae, edge_vae, latents):
+    """Stage 5 of sample.py (lines 286-294): VAE-decode the cascade's latents on the device.
+
+    latents: the dict CascadeSampler.sample returns.  Adds surf_ncs [B,S,32,32,3], edge_ncs [B,S,E,32,3] and
+    edgeV [B,S,E,6] (the vertex half of edgeZV, sample.py:286) and returns the dict.  The token layout of the latents
+    (position-major, channel-minor) is the channels-last layout of the VAE kernels, so no permutes are needed."""
+    out = dict(latents)
+    out["surf_ncs"] = surf_vae.decode_tokens(latents["surfZ"])
+    out["edge_ncs"] = edge_vae.decode_tokens(latents["edgeZV"][..., :12])
+    out["edgeV"] = latents["edgeZV"][..., 12:].contiguous()
+    return out
+
+
 class CascadeSampler:
     """Runs stages 1-4 of sample.py on this rank's slice of the batch and all-gathers the latents."""
 

@@ -350,15 +350,33 @@ class AutoencoderKLFastDecode(_HipVAE):
     def forward(self, z, return_dict=True, generator=None):
         if not z.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
-        dt = self._dtype()
         z_cl = z.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        return self._decode_cl(z_cl).permute(0, 3, 1, 2).contiguous()
+
+    def _decode_cl(self, z_cl):
+        """Channels-last latents [F,4,4,3] -> channels-last point grids [F,32,32,3] (the layout the kernels use)."""
+        dt = self._dtype()
         n = z_cl.shape[0]
         side = z_cl.shape[1] * 2 ** (len(self.block_out) - 1)
         worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        out = torch.cat(outs) if len(outs) > 1 else outs[0]
-        return out.permute(0, 3, 1, 2).contiguous()
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def decode_tokens(self, surfZ):
+        """Token-layout latents [..., 16*3] (position-major, channel-minor: what SurfZNet denoises) -> point grids
+        [..., 32, 32, 3].  Equals sample.py:289-290's `vae(z.unflatten(-1,(16,3)).flatten(0,1).permute(0,2,1)
+        .unflatten(-1,(4,4))).permute(0,2,3,1).unflatten(0,(B,S))` without the two NCHW round trips: the token
+        layout already is the channels-last layout."""
+        if not surfZ.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {surfZ.device})")
+        lead = surfZ.shape[:-1]
+        z_cl = surfZ.detach().to(torch.float32).reshape(-1, 4, 4, self.latent).contiguous()
+        return self._decode_cl(z_cl).reshape(*lead, *self._decode_cl_shape())
+
+    def _decode_cl_shape(self):
+        side = 4 * 2 ** (len(self.block_out) - 1)
+        return (side, side, self.out_ch)
 
 
 class AutoencoderKL1DFastDecode(_HipVAE):
@@ -413,15 +431,28 @@ class AutoencoderKL1DFastDecode(_HipVAE):
     def forward(self, z, return_dict=True):
         if not z.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
-        dt = self._dtype()
         z_cl = z.detach().to(torch.float32).permute(0, 2, 1).contiguous()          # [G, L, 3]
+        return self._decode_cl(z_cl).permute(0, 2, 1).contiguous()
+
+    def _decode_cl(self, z_cl):
+        """Channels-last latents [G,4,3] -> channels-last polylines [G,32,3]."""
+        dt = self._dtype()
         n = z_cl.shape[0]
         length = z_cl.shape[1] * 2 ** len(self.block_out)
         worst = length * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        out = torch.cat(outs) if len(outs) > 1 else outs[0]
-        return out.permute(0, 2, 1).contiguous()
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def decode_tokens(self, edgeZ):
+        """Token-layout latents [..., 4*3] (the first 12 of EdgeZNet's 18 channels) -> polylines [..., 32, 3]; equals
+        sample.py:293-294's `vae(z.unflatten(-1,(4,3)).reshape(-1,4,3).permute(0,2,1)).permute(0,2,1).reshape(B,S,E,32,3)`."""
+        if not edgeZ.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {edgeZ.device})")
+        lead = edgeZ.shape[:-1]
+        z_cl = edgeZ.detach().to(torch.float32).reshape(-1, 4, self.latent).contiguous()
+        out = self._decode_cl(z_cl)
+        return out.reshape(*lead, out.shape[1], out.shape[2])
 
 
 # --------------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 1
+#define BG_ABI_VERSION 2
 
 typedef void* bg_stream_t;              /* hipStream_t */
 
@@ -65,6 +65,36 @@ int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const float* bia
                          int M, int N, int N_pad, int K, int ab_dtype, int out_dtype, int act,
                          const float* add, int ld_add, int add_div, bg_stream_t stream);
 
+/* The same GEMM with every epilogue option of the 16-bit kernels, as one descriptor.  Beyond bg_gemm_bias_act_fwd:
+ *   add2            second fp32 addend, row (m / add2_div)
+ *   out_lo          split output: the fp32 result v is stored as hi = T(v) -> out and lo = T(v - hi) -> out_lo
+ *                   (two 16-bit planes, row stride ldc); hi is directly the next GEMM's A operand
+ *   res_hi, res_lo  split residual addend rows [M,N] (row stride ld_res); may alias out / out_lo (in place)
+ *   stats_out       [N_pad/64][M][2] fp32 (part-major): per 64-column group (sum, sum of squares) of v
+ *   stats_in, colsum  LayerNorm fold: a holds raw (un-normalised) 16-bit rows, w = T(gamma * W), bias = b + W beta,
+ *                   colsum[n] = sum_k w[n,k]; the epilogue computes act(rstd_m * acc - mean_m * rstd_m * colsum[n] +
+ *                   bias[n]) with mean / rstd summed from stats_in [K/64][M][2] (written by a producer's stats_out).
+ * The new options need ab_dtype BG_BF16 | BG_F16, N == N_pad and ldc % 8 == 0. */
+typedef struct {
+    const void* a; int lda;
+    const void* w; const float* bias;
+    void* out; int ldc;
+    int M, N, N_pad, K;
+    int ab_dtype, out_dtype, act;
+    const float* add; int ld_add, add_div;
+    const float* add2; int ld_add2, add2_div;
+    void* out_lo;
+    const void* res_hi; const void* res_lo; int ld_res;
+    float* stats_out;
+    const float* stats_in; const float* colsum; float ln_eps;
+} bg_gemm_desc;
+int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
+
+/* LayerNorm(768) of rows given as the split pair x = hi + lo (two 16-bit planes of dtype `dtype`) -> y (same dtype):
+ * the denoisers' final net.norm when the residual stream is kept split. */
+int bg_layernorm_split_fwd(const void* hi, const void* lo, const float* gamma, const float* beta, void* y, int dtype,
+                           int M, float eps, bg_stream_t stream);
+
 /* F.scaled_dot_product_attention inside nn.MultiheadAttention (network.py:1076-1078 via
  * torch/nn/modules/transformer.py slow path): qkv packed [B*N, 2304] (q|k|v, head h at columns
  * 64h..64h+63 of each third; q already multiplied by 1/8), key_pad uint8 [B,N] (1 = padded key, -inf)
@@ -96,6 +126,12 @@ typedef struct {            /* one nn.TransformerEncoderLayer (norm_first) */
     const float* b_1;
     const void* w_2;        /* [768,1024] */
     const float* b_2;
+    /* LayerNorm fold (16-bit compute dtypes; both NULL = unfolded: the two LayerNorms run as kernels).  When set,
+     * w_qkv = T(norm1.weight * W_in) and b_qkv = b_in + W_in norm1.bias (q parts pre-scaled), likewise w_1 / b_1 with
+     * norm2, and *_colsum[n] = sum_k float(w[n,k]) of the ROUNDED folded weights; the GEMM then takes the raw 16-bit
+     * residual rows and applies mean / rstd per row in its epilogue. */
+    const float* qkv_colsum; /* fp32 [2304] */
+    const float* w1_colsum;  /* fp32 [1024] */
 } bg_layer_weights;
 
 typedef struct {

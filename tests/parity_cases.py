@@ -160,6 +160,68 @@ def pndm_case(n_steps=209, shape=(3, 30, 6), guidance=None, seed=0):
             "mean_abs": worst}
 
 
+def _split(x, dt):
+    hi = x.to(dt)
+    return hi, (x - hi.float()).to(dt)
+
+
+def gemm_split_case(M, dtype, K=768, N=768, with_res=True, seed=0):
+    """Split-residual producer epilogue: hi/lo planes + per-64-column row statistics vs plain torch fp32 math."""
+    g = gen(seed)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    bias = torch.randn(N, generator=g)
+    x = torch.randn(M, N, generator=g) * 3 + 0.7
+    hi, lo = _split(x, dtype)
+    kw = dict(res=(hi.to(DEV), lo.to(DEV))) if with_res else dict(add=x.to(DEV))
+    r = ops.linear_ex(a.to(DEV), w.to(DEV), bias.to(DEV), split_out=True, want_stats=True, **kw)
+    want = a.double() @ w.double().t() + bias.double() + ((hi.double() + lo.double()) if with_res else x.double())
+    got = r["out"].double().cpu() + r["lo"].double().cpu()
+    st = r["stats"].double().cpu().permute(1, 0, 2)             # part-major on the device
+    grp = want.reshape(M, N // 64, 64)
+    return {"hi": r["out"], "lo": r["lo"], "stats": r["stats"],
+            "max_abs": float((got - want).abs().max()),
+            "hi_is_rounding": bool((r["out"].cpu().float() - want.float().to(dtype).float()).abs().max() <= 2 * float(want.abs().max()) * 2 ** -8),
+            "stats_sum_err": float((st[..., 0] - grp.sum(-1)).abs().max()),
+            "stats_sq_rel": float(((st[..., 1] - (grp * grp).sum(-1)).abs() / (grp * grp).sum(-1)).max())}
+
+
+def gemm_fold_case(M, N, dtype, act=0, seed=0):
+    """LayerNorm-fold consumer epilogue vs (a) the same algebra in fp64 and (b) LayerNorm(x) @ W^T + b itself."""
+    g = gen(seed)
+    K = 768
+    x = torch.randn(M, K, generator=g) * 2.5 + torch.randn(M, 1, generator=g)      # per-row mean up to ~1 sigma/2
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    W, b = torch.randn(N, K, generator=g) * 0.04, torch.randn(N, generator=g) * 0.1
+    hi, _ = _split(x, dtype)
+    grp = x.reshape(M, K // 64, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous()    # [12, M, 2]
+    Wp = (W * gamma[None]).to(dtype)
+    colsum = Wp.float().sum(1)
+    c = b + W @ beta
+    r = ops.linear_ex(hi.to(DEV), Wp.to(DEV), c.to(DEV), act=act, stats_in=stats.to(DEV), colsum=colsum.to(DEV))
+    got = r["out"].double().cpu()
+    mean = x.double().mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.double().var(-1, unbiased=False, keepdim=True) + 1e-5)
+    alg = rstd * (hi.double() @ Wp.double().t()) - mean * rstd * colsum.double()[None] + c.double()[None]
+    ln = ((x.double() - mean) * rstd * gamma.double() + beta.double()) @ W.double().t() + b.double()
+    if act:
+        alg, ln = alg.clamp(min=0), ln.clamp(min=0)
+    scale = float(ln.abs().max())
+    return {"out": r["out"], "vs_algebra": float((got - alg).abs().max()) / scale,
+            "vs_layernorm": float((got - ln).abs().max()) / scale}
+
+
+def layernorm_split_case(M, dtype, seed=0):
+    g = gen(seed)
+    x = torch.randn(M, 768, generator=g) * 2 + 0.3
+    hi, lo = _split(x, dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    got = ops.layernorm_split(hi.to(DEV), lo.to(DEV), gamma.to(DEV), beta.to(DEV))
+    want = torch.nn.functional.layer_norm(hi.float() + lo.float(), (768,), gamma, beta, 1e-5)
+    return _err(got.float(), want)
+
+
 # ---------------------------------------------------------------------------------------------------
 NETS = {"SurfPosNet": bga.SurfPosNet, "SurfZNet": bga.SurfZNet, "EdgePosNet": bga.EdgePosNet, "EdgeZNet": bga.EdgeZNet}
 MANIFEST = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
