@@ -157,10 +157,10 @@ __device__ __forceinline__ float2 ln_fold_coeffs(float S, float Q, int K, float 
     const float rstd = 1.0f / sqrtf(var + eps);
     return make_float2(rstd, -(mean * rstd));
 }
-// LayerNorm fold applied to one accumulator: rstd * acc + (-mean * rstd * colsum + bias')   (no fma contraction)
+// LayerNorm fold applied to one accumulator: rstd * acc + (-mean * rstd * colsum + bias'), as two explicit fmas (the
+// build runs with -ffp-contract=off, so every kernel that calls this rounds identically)
 __device__ __forceinline__ float ln_fold_apply(float acc, float rstd, float nmr, float colsum, float bias) {
-    const float t = nmr * colsum + bias;
-    return acc * rstd + t;
+    return __builtin_fmaf(acc, rstd, __builtin_fmaf(nmr, colsum, bias));
 }
 int gemm_f32(const GemmArgs& g, hipStream_t s);
 int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s);   // ab_dtype: BG_BF16 | BG_F16

@@ -470,7 +470,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
             }
         };
-        // LayerNorm fold (consumer): lane l owns the statistics of row rbase + l; its <= 16 partial pairs are requested
+        // per-column epilogue vectors (bias; LayerNorm fold: column sums) are requested there too: loaded in the
+        // epilogue itself they would expose one L2 round trip per tile
+        float bias_l[TN] = {0.f, 0.f}, cs_l[TN] = {0.f, 0.f};
+        auto load_cols = [&]() {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (g.bias) bias_l[j] = g.bias[cbase + j * 32 + (lane & 31)];
+                if (FOLD) cs_l[j] = g.colsum[cbase + j * 32 + (lane & 31)];
+            }
+        };
+        // LayerNorm fold (consumer): lane l owns the statistics of row rbase + l; its 12 partial pairs are requested
         // at the start of the last K-step as well
         float2 st[16];
         auto load_stats = [&]() {
@@ -497,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     set_src(m0, n0);
                     issue(slot ^ 1, 0);
                 }
+                load_cols();
                 if (!FAST && has_res) { load_res(0, 0); load_res(1, 1); }
                 if (FOLD) load_stats();
             }
@@ -535,41 +546,41 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         if (INSTR) te = __builtin_amdgcn_s_memtime();
 
         // ---------------- epilogue (wave-private patch; the ring already receives the next tile) ----------------
-        float bias_l[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bias_l[j] = g.bias ? g.bias[cbase + j * 32 + (lane & 31)] : 0.f;
         if (half_fast) {
             T* out = reinterpret_cast<T*>(g.out);
             constexpr bool fold = FOLD;
             float2 cf = make_float2(1.f, 0.f);                    // (rstd, -mean * rstd) of row rbase + lane
-            float cs_l[TN] = {0.f, 0.f};
             if (fold) {
                 float ps[16], pq[16];
 #pragma unroll
                 for (int p = 0; p < 16; ++p) { ps[p] = st[p].x; pq[p] = st[p].y; }
                 cf = ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+            }
+            // every lane needs the coefficients of its 2 x 16 accumulator rows: 64 float2 go through the (not yet
+            // used) patch, read back as broadcasts (all lanes of a half wave read the same address)
+            float2 cAB[TM][16];
+            if (fold) {
+                float2* pc = reinterpret_cast<float2*>(patch);
+                pc[lane] = cf;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < TN; ++j) cs_l[j] = g.colsum[cbase + j * 32 + (lane & 31)];
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cAB[i][r] = pc[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                float cA[16], cB[16];                             // coefficients of this lane's 16 accumulator rows
-                if (fold) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int src = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        cA[r] = __shfl(cf.x, src, 64);
-                        cB[r] = __shfl(cf.y, src, 64);
-                    }
-                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int rp = 0; rp < 8; ++rp) {
                         float a, b;
                         if (fold) {
-                            a = ln_fold_apply(acc[i][j][2 * rp], cA[2 * rp], cB[2 * rp], cs_l[j], bias_l[j]);
-                            b = ln_fold_apply(acc[i][j][2 * rp + 1], cA[2 * rp + 1], cB[2 * rp + 1], cs_l[j], bias_l[j]);
+                            a = ln_fold_apply(acc[i][j][2 * rp], cAB[i][2 * rp].x, cAB[i][2 * rp].y, cs_l[j], bias_l[j]);
+                            b = ln_fold_apply(acc[i][j][2 * rp + 1], cAB[i][2 * rp + 1].x, cAB[i][2 * rp + 1].y, cs_l[j], bias_l[j]);
                         } else {
                             a = acc[i][j][2 * rp] + bias_l[j]; b = acc[i][j][2 * rp + 1] + bias_l[j];
                         }
@@ -605,7 +616,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
             // row, so hi and lo leave as 16-byte stores of 128-byte row segments, the residual arrives the same way,
             // and one 8-lane butterfly yields the row's (sum, sum of squares) over this wave's 64 columns.
             float* pf = reinterpret_cast<float*>(patch);
-            float2 row_sq = make_float2(0.f, 0.f);               // (sum, sum of squares) of wave-tile row `lane`
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int i = t >> 1, half = t & 1;
@@ -657,9 +667,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                         const float q8 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
                                          ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
                         const float S = group8_sum(s8), Q = group8_sum(q8);
-                        // row t*16 + it*8 + (lane >> 3) is complete in its 8 lanes; hand it to lane == row
-                        const float Sx = __shfl(S, (lane & 7) * 8, 64), Qx = __shfl(Q, (lane & 7) * 8, 64);
-                        if ((lane >> 3) == t * 2 + it) row_sq = make_float2(Sx, Qx);
+                        // part-major [N/64][M] pairs: the 8 rows of this group are 64 contiguous bytes
+                        if (row_ok && (lane & 7) == 0)
+                            reinterpret_cast<float2*>(g.stats_out)[(size_t)(cbase / 64) * g.M + grow] = make_float2(S, Q);
                     }
                     if (row_ok) {
                         const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
@@ -674,8 +684,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
-            if (g.stats_out && rbase + lane < g.M)               // part-major [N/64][M] pairs: one 512-byte store per wave
-                reinterpret_cast<float2*>(g.stats_out)[(size_t)(cbase / 64) * g.M + rbase + lane] = row_sq;
         } else {
             float* pf = reinterpret_cast<float*>(patch);
 #pragma unroll
