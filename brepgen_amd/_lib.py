@@ -19,7 +19,8 @@ vp, fp, i64p, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device po
 
 class MlpWeights(C.Structure):
     _fields_ = [("w0", vp), ("b0", fp), ("ln_g", fp), ("ln_b", fp), ("w3", vp), ("b3", fp),
-                ("k_in", C.c_int), ("n_out", C.c_int), ("n_out_pad", C.c_int), ("w0_dtype", C.c_int)]
+                ("k_in", C.c_int), ("n_out", C.c_int), ("n_out_pad", C.c_int), ("w0_dtype", C.c_int),
+                ("w0_mfma", fp)]
 
 
 class LayerWeights(C.Structure):
@@ -69,6 +70,7 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, vp]),
     "bg_gemm_ex_fwd": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
+    "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_denoiser_fwd": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenoiserInputs), fp, vp, C.c_size_t, vp]),

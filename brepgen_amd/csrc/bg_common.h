@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -171,6 +171,10 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
 // same, input rows given as the split pair x = hi + lo (16-bit planes of dtype y_dtype)
 int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
                        float eps, hipStream_t s);
+// h = SiLU(LayerNorm(x W0^T + b0)) for k in {6, 12, 48}; w0p = W0 in MFMA operand order (embed.hip)
+bool embed_ln_silu_supported(int k);
+int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
+                  const float* b, void* out, int out_dtype, float eps, hipStream_t s);
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s);
 int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
 // c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)

@@ -34,7 +34,7 @@ ProfRec* g_recs = nullptr;
 int g_cap = 0, g_n = 0;
 bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(128x64)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
-                                          "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc"};
+                                          "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {
@@ -105,12 +105,20 @@ struct Ctx {
 static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, int rows, float* out, int ldc,
                      const float* add, int ld_add, int add_div, const float* add2, int ld_add2, int add2_div,
                      bool to_stream = false) {
-    float* t0 = reinterpret_cast<float*>(c.R);
-    GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
-    int rc = gemm(g1, m.w0_dtype, c.s);
-    if (rc) return rc;
-    rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s);
-    if (rc) return rc;
+    int rc;
+    if (m.w0_mfma && m.w0_dtype == BG_F32 && embed_ln_silu_supported(m.k_in)) {
+        // input embeds (k = 6 / 12 / 48): Linear + LayerNorm + SiLU in one kernel, nothing but the result written
+        rc = embed_ln_silu(reinterpret_cast<const float*>(x), lda, rows, m.k_in, m.w0_mfma, m.b0, m.ln_g, m.ln_b, c.H,
+                           c.dtype, 1e-5f, c.s);
+        if (rc) return rc;
+    } else {
+        float* t0 = reinterpret_cast<float*>(c.R);
+        GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
+        rc = gemm(g1, m.w0_dtype, c.s);
+        if (rc) return rc;
+        rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s);
+        if (rc) return rc;
+    }
     GemmArgs g2{c.H, 768, m.w3, m.b3, out, ldc, rows, m.n_out, m.n_out_pad, 768, BG_F32, BG_ACT_NONE, add, ld_add,
                 add ? add_div : 1};
     g2.add2 = add2; g2.ld_add2 = ld_add2; g2.add2_div = add2 ? add2_div : 1;

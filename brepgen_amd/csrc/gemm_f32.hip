@@ -72,11 +72,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// M <= 8 (the time-embedding MLP: one row per distinct timestep, usually 1): a 64x64-tile GEMM would run 12 blocks
+// through a 48-step latency chain.  Here one wave owns one output column: lanes stride over K (coalesced 256-byte
+// reads of the weight row), fma-accumulate, butterfly-reduce.
+__global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
+    const float* __restrict__ A = reinterpret_cast<const float*>(g.a);
+    const float* __restrict__ W = reinterpret_cast<const float*>(g.w);
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= g.N) return;
+    const float* wr = W + (size_t)n * g.K;
+    const float bias = g.bias ? g.bias[n] : 0.f;
+    for (int m = 0; m < g.M; ++m) {
+        const float* ar = A + (size_t)m * g.lda;
+        float s = 0.f;
+        for (int k = lane; k < g.K; k += 64) s = __builtin_fmaf(ar[k], wr[k], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            float v = s + bias;
+            if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+            if (g.add) v += g.add[(size_t)(m / g.add_div) * g.ld_add + n];
+            if (g.add2) v += g.add2[(size_t)(m / g.add2_div) * g.ld_add2 + n];
+            if (g.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(g.out)[(size_t)m * g.ldc + n] = (__bf16)v;
+            else if (g.out_dtype == BG_F16) reinterpret_cast<_Float16*>(g.out)[(size_t)m * g.ldc + n] = (_Float16)v;
+            else reinterpret_cast<float*>(g.out)[(size_t)m * g.ldc + n] = v;
+        }
+    }
+}
+
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.out_lo || g.res_hi || g.stats_out || g.stats_in) {
         set_error("gemm_f32: split residual / LayerNorm fold exist for 16-bit operands only");
         return BG_E_DTYPE;
+    }
+    if (g.M <= 8 && g.K >= 64) {
+        ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K, 4.0 * g.N * (double)g.K, s);
+        hipLaunchKernelGGL(gemv_f32_kernel, dim3((g.N + 3) / 4), dim3(256), 0, s, g);
+        return launch_status("gemv_f32");
     }
     const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;

@@ -108,6 +108,21 @@ def layernorm_split(hi, lo, gamma, beta, eps=1e-5):
     return y
 
 
+def embed_ln_silu(x, k, w0, b0, gamma, beta, out_dtype=torch.float32, eps=1e-5):
+    """SiLU(LayerNorm(x[:, :k] @ w0.T + b0)) through the fused kernel; x fp32 [rows, lda >= k] (a column-offset view
+    with unit column stride is fine), w0 fp32 [768, k]."""
+    from .network import mfma_operand_order
+    _need_cuda(x, w0, b0, gamma, beta)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and w0.shape == (768, k)
+    rows, lda = x.shape[0], x.stride(0)
+    w0p = mfma_operand_order(w0.to(torch.float32))
+    out = torch.empty(rows, 768, device=x.device, dtype=out_dtype)
+    check(_lib.load().bg_embed_ln_silu_fwd(x.data_ptr(), lda, rows, k, ptr(w0p), ptr(b0.contiguous()),
+                                           ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(out),
+                                           bg_dtype(out_dtype), eps, stream()), "bg_embed_ln_silu_fwd")
+    return out
+
+
 def attention(qkv, key_pad, B, N):
     """qkv [B*N, 2304] (q pre-scaled by 1/8), key_pad bool/uint8 [B,N] or None -> [B*N, 768]."""
     _need_cuda(qkv, key_pad)

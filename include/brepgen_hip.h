@@ -95,6 +95,13 @@ int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
 int bg_layernorm_split_fwd(const void* hi, const void* lo, const float* gamma, const float* beta, void* y, int dtype,
                            int M, float eps, bg_stream_t stream);
 
+/* First half of an input-embedding MLP, fused: out = SiLU(LayerNorm(x W0^T + b0)), x fp32 [rows, lda] (k in {6,12,48}
+ * leading columns used), exact-fp32 matrix-core arithmetic, out [rows,768] fp32 / bf16 / fp16 (sub-keys .0 .1 + SiLU
+ * of p_embed, z_embed, surfp_embed, surfz_embed, edgep_embed, edgez_embed, vertp_fc: network.py:1080-1085 etc.).
+ * w0_mfma: see bg_mlp_weights. */
+int bg_embed_ln_silu_fwd(const float* x, int lda, int rows, int k, const float* w0_mfma, const float* b0,
+                         const float* ln_g, const float* ln_b, void* out, int out_dtype, float eps, bg_stream_t stream);
+
 /* F.scaled_dot_product_attention inside nn.MultiheadAttention (network.py:1076-1078 via
  * torch/nn/modules/transformer.py slow path): qkv packed [B*N, 2304] (q|k|v, head h at columns
  * 64h..64h+63 of each third; q already multiplied by 1/8), key_pad uint8 [B,N] (1 = padded key, -inf)
@@ -114,6 +121,9 @@ typedef struct {            /* Linear(k_in,768) -> LayerNorm -> SiLU -> Linear(7
     const void* w3;         /* compute dtype [n_out_pad,768] */
     const float* b3;        /* fp32 [n_out_pad] */
     int k_in, n_out, n_out_pad, w0_dtype;
+    const float* w0_mfma;   /* optional, k_in in {6,12,48} with fp32 w0: W0 in MFMA operand order,
+                               [24][k_in/2][64] with element (ct, kk, lane) = w0[ct*32 + (lane & 31)][2*kk + (lane >> 5)]:
+                               selects the fused Linear + LayerNorm + SiLU kernel (bg_embed_ln_silu_fwd) */
 } bg_mlp_weights;
 
 typedef struct {            /* one nn.TransformerEncoderLayer (norm_first) */

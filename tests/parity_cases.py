@@ -160,6 +160,20 @@ def pndm_case(n_steps=209, shape=(3, 30, 6), guidance=None, seed=0):
             "mean_abs": worst}
 
 
+def embed_case(rows, k, out_dtype, lda=None, col0=0, seed=0):
+    """Fused Linear(k) + LayerNorm + SiLU vs plain torch fp64 math."""
+    g = gen(seed)
+    lda = lda or k
+    xfull = torch.randn(rows, lda, generator=g) * 1.5
+    w0, b0 = torch.randn(768, k, generator=g) * 0.3, torch.randn(768, generator=g) * 0.1
+    gamma, beta = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    xd = xfull.to(DEV)
+    got = ops.embed_ln_silu(xd[:, col0:], k, w0.to(DEV), b0.to(DEV), gamma.to(DEV), beta.to(DEV), out_dtype)
+    x = xfull[:, col0:col0 + k].double()
+    h = torch.nn.functional.layer_norm(x @ w0.double().t() + b0.double(), (768,), gamma.double(), beta.double(), 1e-5)
+    return _err(got.float(), torch.nn.functional.silu(h).float())
+
+
 def _split(x, dt):
     hi = x.to(dt)
     return hi, (x - hi.float()).to(dt)

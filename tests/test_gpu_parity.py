@@ -118,6 +118,21 @@ def test_attention_fp32(pc, N):
     assert e["finite"] and e["max_abs"] < 1e-5
 
 
+# ---- fused input-embed kernel: Linear(k) + LayerNorm + SiLU (csrc/embed.hip) --------------------------------
+@pytest.mark.parametrize("k", [6, 12, 48])
+@pytest.mark.parametrize("rows", [1, 33, 1000])
+def test_embed_ln_silu_fp32(pc, k, rows):
+    e = pc.embed_case(rows, k, F32)
+    assert e["finite"] and e["max_abs"] < 2e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(BF16, 2e-2), (F16, 3e-3)])
+def test_embed_ln_silu_16bit_and_strided_input(pc, dtype, tol):
+    assert pc.embed_case(257, 48, dtype)["max_abs"] < tol
+    assert pc.embed_case(100, 6, dtype, lda=18, col0=12)["max_abs"] < tol      # vertp_fc reads x[:, 12:18]
+    assert pc.embed_case(100, 12, F32, lda=18)["max_abs"] < 2e-5               # edgez_embed reads x[:, :12]
+
+
 # ---- split residual stream + LayerNorm fold (16-bit modes) ---------------------------
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("with_res", [True, False])
