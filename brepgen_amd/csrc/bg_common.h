@@ -105,6 +105,10 @@ struct GemmArgs {
     // colsum[n] = sum_k w[n,k];  out = act(rstd_m * acc - mean_m * rstd_m * colsum[n] + bias[n]) with the row
     // statistics summed from stats_in [K/64][M][2].
     const float* stats_in = nullptr; const float* colsum = nullptr; float ln_eps = 1e-5f;
+    // fp32 operands, M <= 8: allow the wave-per-column GEMV (tree reduction over K instead of the MFMA's k-ordered fma
+    // chain -- last-bit different, so only callers whose M never depends on the batch composition set it: the
+    // time-embedding MLP)
+    int gemv_ok = 0;
 };
 
 // 4 x 16-bit (bf16 | fp16) payload <-> floats

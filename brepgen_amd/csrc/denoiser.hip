@@ -114,6 +114,7 @@ static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, in
     } else {
         float* t0 = reinterpret_cast<float*>(c.R);
         GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
+        g1.gemv_ok = (&m == &c.w->time_embed);                    // one row per distinct timestep
         rc = gemm(g1, m.w0_dtype, c.s);
         if (rc) return rc;
         rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s);

@@ -48,6 +48,16 @@ __global__ __launch_bounds__(512) void embed_ln_silu_kernel(const float* __restr
 #pragma unroll
     for (int kk = 0; kk < K2; ++kk) a[kk] = xr[2 * kk];
 
+    // per-column vectors first: their L2 round trip overlaps the MFMA chain instead of following it
+    float bias[TPW], gcol[TPW], bcol[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int col = (wave * TPW + t) * 32 + c;
+        bias[t] = b0[col];
+        gcol[t] = gam[col];
+        bcol[t] = bet[col];
+    }
+
     f32x16 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -60,16 +70,10 @@ __global__ __launch_bounds__(512) void embed_ln_silu_kernel(const float* __restr
     }
 
     // C layout: column = ct*32 + c, row = (r & 3) + 8 * (r >> 2) + 4 * h
-    float gcol[TPW], bcol[TPW];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int col = (wave * TPW + t) * 32 + c;
-        const float bias = b0[col];
-        gcol[t] = gam[col];
-        bcol[t] = bet[col];
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += bias;
-    }
+        for (int r = 0; r < 16; ++r) acc[t][r] += bias[t];
 
     // ---- LayerNorm statistics, two-pass in registers ----
     float mean[16], rstd[16];

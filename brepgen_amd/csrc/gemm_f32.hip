@@ -106,7 +106,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         set_error("gemm_f32: split residual / LayerNorm fold exist for 16-bit operands only");
         return BG_E_DTYPE;
     }
-    if (g.M <= 8 && g.K >= 64) {
+    if (g.gemv_ok && g.M <= 8 && g.K >= 64) {
         ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K, 4.0 * g.N * (double)g.K, s);
         hipLaunchKernelGGL(gemv_f32_kernel, dim3((g.N + 3) / 4), dim3(256), 0, s, g);
         return launch_status("gemv_f32");

@@ -165,11 +165,11 @@ class _HipDenoiser(nn.Module):
                 wq[:D] *= 0.125
                 L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D, gamma=layer.norm1.weight)
                 L.qkv_colsum = f32(keep[-1].to(torch.float32).sum(1))
-                L.b_qkv = f32(bq + wq @ layer.norm1.bias.detach().to(torch.float32))
+                L.b_qkv = f32(bq + (wq * layer.norm1.bias.detach().to(torch.float32)[None, :]).sum(1))
                 w1 = layer.linear1.weight.detach().to(torch.float32)
                 L.w_1 = mat(layer.linear1.weight, gamma=layer.norm2.weight)
                 L.w1_colsum = f32(keep[-1].to(torch.float32).sum(1))
-                L.b_1 = f32(layer.linear1.bias.detach().to(torch.float32) + w1 @ layer.norm2.bias.detach().to(torch.float32))
+                L.b_1 = f32(layer.linear1.bias.detach().to(torch.float32) + (w1 * layer.norm2.bias.detach().to(torch.float32)[None, :]).sum(1))
             else:
                 L.w_qkv = mat(layer.self_attn.in_proj_weight, scale_rows=D)
                 L.b_qkv = f32(bq)
