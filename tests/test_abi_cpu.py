@@ -42,6 +42,39 @@ def test_argument_errors_are_negative_and_explained():
     assert lib.bg_denoiser_fwd(C.byref(w), C.byref(i), None, None, 0, None) < 0
 
 
+def test_gemm_ex_rejects_inconsistent_epilogue_options():
+    """bg_gemm_ex_fwd validates the split-residual / LayerNorm-fold combinations before anything is launched."""
+    lib = _lib.load()
+    fake = 0x10000                                   # aligned, never dereferenced: validation fails first
+
+    def desc(**kw):
+        d = _lib.GemmDesc()
+        d.a, d.lda, d.w, d.bias, d.out, d.ldc = fake, 768, fake, fake, fake, 768
+        d.M, d.N, d.N_pad, d.K = 256, 768, 768, 768
+        d.ab_dtype, d.out_dtype, d.act = _lib.BG_BF16, _lib.BG_BF16, 0
+        d.add_div = d.add2_div = 1
+        d.ln_eps = 1e-5
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    bad = [desc(stats_in=fake),                                  # fold without column sums
+           desc(stats_in=fake, colsum=fake, out_lo=fake),        # fold and split output together
+           desc(stats_in=fake, colsum=fake, out_dtype=_lib.BG_F32),
+           desc(res_hi=fake, res_lo=fake, ld_res=768),           # split residual needs a split output
+           desc(out_lo=fake, res_hi=fake, ld_res=768),           # hi plane without lo plane
+           desc(stats_out=fake),                                 # row statistics only with a split output
+           desc(out_lo=fake, out_dtype=_lib.BG_F32),
+           desc(out_lo=fake, N=700)]                             # N != N_pad
+    for d in bad:
+        rc = lib.bg_gemm_ex_fwd(C.byref(d), None)
+        assert rc < 0, rc
+        assert lib.bg_last_error()
+    d = desc(out_lo=fake, ab_dtype=_lib.BG_F32, out_dtype=_lib.BG_F32)
+    assert lib.bg_gemm_ex_fwd(C.byref(d), None) == -4            # BG_E_DTYPE: 16-bit operands only
+    assert lib.bg_embed_ln_silu_fwd(fake, 5, 4, 5, fake, fake, fake, fake, fake, _lib.BG_BF16, 1e-5, None) == -2   # k = 5
+
+
 def test_workspace_bytes_scales_with_tokens():
     lib = _lib.load()
     a = lib.bg_workspace_bytes(_lib.BG_SURFZ, 512, 60, 1, _lib.BG_BF16)

@@ -118,3 +118,39 @@ def test_device_dedup_is_bit_identical_to_the_numpy_loops():
         odd = torch.zeros(B, S, dtype=torch.bool)
         odd[:, ::3] = True
         assert torch.equal(dedup_edges(ep.cuda(), odd.cuda(), 0.08).cpu(), dedup_edges_host(ep, odd, 0.08))
+
+
+def test_pipeline_driver_end_to_end(tmp_path):
+    """brepgen_amd.pipeline: eval_config.yaml + .pt files on disk -> cascade + VAE decode -> the arrays of sample.py:286-299.
+    Weights are seeded reference-keyed state dicts written with torch.save (the VAE files hold encoder + decoder)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import yaml
+    from brepgen_amd import pipeline
+    from oracle import denoisers as orc
+    from oracle import vae as ov
+    names = {"surfpos_weight": "SurfPosNet", "surfz_weight": "SurfZNet", "edgepos_weight": "EdgePosNet", "edgez_weight": "EdgeZNet"}
+    args = {"batch_size": 2, "z_threshold": 0.2, "bbox_threshold": 0.08, "num_surfaces": 3, "num_edges": 3, "use_cf": True,
+            "class_label": "table", "save_folder": str(tmp_path / "out")}
+    for i, (k, net) in enumerate(names.items()):
+        args[k] = f"{k}.pt"
+        torch.save(orc.seeded_state_dict(net, 90 + i, True), tmp_path / args[k])
+    for k, dec, enc in (("surfvae_weight", ov.surf_decoder_spec(), ov.surf_encoder_spec()),
+                        ("edgevae_weight", ov.edge_decoder_spec(), ov.edge_encoder_spec())):
+        full = dict(ov.seeded_state_dict(dec, 5))
+        full.update(ov.seeded_state_dict(enc, 6))
+        args[k] = f"{k}.pt"
+        torch.save(full, tmp_path / args[k])
+    cfg = tmp_path / "eval_config.yaml"
+    cfg.write_text(yaml.safe_dump({"furniture": args}))
+    eval_args = pipeline.load_eval_args(str(cfg), "furniture")
+    sampler, surf_vae, edge_vae = pipeline.build(eval_args, "cuda", None, torch.float16, str(tmp_path))
+    assert sampler.use_cf and sampler.class_id == 10
+    out = pipeline.sample_batch(sampler, surf_vae, edge_vae, eval_args, torch.Generator().manual_seed(4),
+                                pndm_pos_steps=13, ddpm_pos_steps=3, pndm_z_steps=13)
+    B, S, E = 2, 3, 3                                   # use_cf: no late doubling of the faces (sample.py:140-142)
+    assert out["surfPos"].shape == (B, S, 6) and out["surf_ncs"].shape == (B, S, 32, 32, 3)
+    assert out["edge_pos"].shape == (B, S, E, 6) and out["edge_ncs"].shape == (B, S, E, 32, 3)
+    assert out["edge_z"].shape == (B, S, E, 12) and out["edgeV"].shape == (B, S, E, 6)
+    assert out["surfMask"].dtype == np.bool_ and out["edge_mask"].shape == (B, S, E)
+    assert all(np.isfinite(v).all() for k, v in out.items() if v.dtype != np.bool_)
