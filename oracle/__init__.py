@@ -8,7 +8,7 @@ Pinning status
 --------------
 * ``oracle.denoisers`` — PINNED: validated against the reference's own
   ``network.py`` classes (imported in the build container with the missing
-  ``diffusers`` package stubbed out, see ``tools/gen_golden.py``) and against
+  ``diffusers`` package stubbed out, see ``tests/golden/gen_golden.py``) and against
   the golden vectors that script wrote to ``tests/golden/``.
 * ``oracle.schedulers`` — PARITY UNPINNED: the arithmetic lives in the
   third-party ``diffusers==0.27`` package (``requirements.txt:5`` of the

@@ -5,7 +5,7 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Every function takes a flat
 plain tensors, and spells the arithmetic out op by op -- no ``nn.Module``, no
 ``nn.TransformerEncoder`` -- so that it is an independent statement of what the
 reference computes.  Pinned against the reference classes themselves by
-``tools/gen_golden.py`` (max-abs diff recorded in ``tests/golden/MANIFEST.json``).
+``tests/golden/gen_golden.py`` (max-abs diff recorded in ``tests/golden/MANIFEST.json``).
 
 Reference locations (all in /root/reference):
   sincos_embedding          network.py:1043-1063

@@ -14,7 +14,7 @@ and store inputs + output in ``tests/golden/<case>.npz``.  The oracle
 restatement is checked against the same outputs here and the max-abs diff goes
 into ``tests/golden/MANIFEST.json``.
 
-    python tools/gen_golden.py
+    python tests/golden/gen_golden.py
 """
 import importlib
 import json
@@ -25,7 +25,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -115,7 +115,7 @@ def main():
 
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(False)
-    manifest = {"generator": "tools/gen_golden.py", "torch": torch.__version__,
+    manifest = {"generator": "tests/golden/gen_golden.py", "torch": torch.__version__,
                 "reference": "samxuxiang/BrepGen @ 2024_08_07 network.py (diffusers imports stubbed)",
                 "cases": {}}
     for name, cls, use_cf, wseed, kw in cases():

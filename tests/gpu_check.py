@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One-shot GPU diagnostic: every parity measurement + per-kernel timings, nothing asserted.
 
-    gpurun -- 'python tools/gpu_check.py > gpurun_out/check.log 2>&1'
+    gpurun -- 'python tests/gpu_check.py > gpurun_out/check.log 2>&1'
 
 Each section is wrapped so one failing kernel does not hide the others.
 """

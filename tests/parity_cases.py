@@ -1,7 +1,7 @@
 """Parity measurements: HIP path (through the C ABI) vs the CPU oracle / plain torch fp32 restatements.
 
 Every function returns a dict of error metrics; ``tests/test_gpu_*.py`` assert on them and
-``tools/gpu_check.py`` prints them all (one gpurun call gives the whole picture).  Needs a GPU.
+``tests/gpu_check.py`` prints them all (one gpurun call gives the whole picture).  Needs a GPU.
 """
 import json
 import math
@@ -251,7 +251,7 @@ def build_net(net, seed, use_cf, dtype):
 
 
 def golden_case(name, dtype):
-    """HIP denoiser vs the golden output written by the reference's own class (tools/gen_golden.py)."""
+    """HIP denoiser vs the golden output written by the reference's own class (tests/golden/gen_golden.py)."""
     meta = MANIFEST["cases"][name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     args = [torch.from_numpy(z[k]).to(DEV) if k in z.files else None for k in meta["args"]]

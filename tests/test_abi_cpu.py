@@ -143,3 +143,12 @@ def test_product_does_not_import_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    # tools/ (micro-benchmarks, profiling helpers) stays clear of the checker as well; bench.py may use it in its
+    # cpu_baseline leg only, __graft_entry__ in smoke() only
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+(oracle|parity_cases)", src, flags=re.M), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)(from|import)\s+oracle", bench, flags=re.M):
+        assert len(m.group(1)) > 0 and "def cpu_baseline" in bench[:m.start()], "oracle import outside cpu_baseline()"

@@ -1,5 +1,5 @@
 """The oracle restatement vs the golden vectors written by the reference's own classes
-(tools/gen_golden.py).  CPU only."""
+(tests/golden/gen_golden.py).  CPU only."""
 import json
 import os
 
