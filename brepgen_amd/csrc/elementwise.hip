@@ -300,6 +300,65 @@ extern "C" int bg_layernorm_fwd(const float* x, const float* gamma, const float*
     return bg::layernorm768(x, gamma, beta, y, y_dtype, M, eps, fuse_silu, (hipStream_t)stream);
 }
 
+namespace bg {
+// Masked mean-squared error of the trainers' loss / validation forward (trainer.py:354, 538, 597, 950-952):
+// rows with row_mask != 0 are skipped, columns [col0, col0 + ncols) are compared.  Deterministic: a fixed grid writes
+// per-block (sum of squares, valid rows) partials in double, one block adds them in a fixed order.
+constexpr int MSE_BLOCKS = 512;
+__global__ __launch_bounds__(256) void masked_sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const uint8_t* __restrict__ mask, long long rows, int ld,
+                                                            int col0, int ncols, double* __restrict__ partial) {
+    __shared__ double sh[2][256];
+    double s = 0.0, n = 0.0;
+    for (long long r = blockIdx.x * 256ll + threadIdx.x; r < rows; r += 256ll * MSE_BLOCKS) {
+        if (mask != nullptr && mask[r]) continue;
+        const float* pa = a + r * ld + col0;
+        const float* pb = b + r * ld + col0;
+        float q = 0.f;
+        for (int c = 0; c < ncols; ++c) { const float d = pa[c] - pb[c]; q += d * d; }
+        s += (double)q;
+        n += 1.0;
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sh[0][0]; partial[2 * blockIdx.x + 1] = sh[1][0]; }
+}
+__global__ __launch_bounds__(256) void masked_mse_final_kernel(const double* __restrict__ partial, int ncols,
+                                                               float* __restrict__ out) {
+    __shared__ double sh[2][256];
+    double s = 0.0, n = 0.0;
+    for (int i = threadIdx.x; i < MSE_BLOCKS; i += 256) { s += partial[2 * i]; n += partial[2 * i + 1]; }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double S = sh[0][0], N = sh[1][0];
+        out[0] = N > 0.0 ? (float)(S / (N * ncols)) : 0.f;      // nn.MSELoss()(pred[~mask], target[~mask])
+        out[1] = (float)(S / ncols);                            // mse(reduction='none')(...).mean(-1).sum()
+        out[2] = (float)N;                                      // valid rows
+    }
+}
+}  // namespace bg
+
+extern "C" int bg_masked_mse(const float* pred, const float* target, const uint8_t* row_mask, long long rows, int ld,
+                             int col0, int ncols, double* scratch, float* out3, bg_stream_t stream) {
+    BG_REQUIRE(pred && target && scratch && out3, BG_E_ARG, "bg_masked_mse: null pointer");
+    BG_REQUIRE(rows >= 0 && ncols > 0 && col0 >= 0 && col0 + ncols <= ld, BG_E_SHAPE,
+               "bg_masked_mse: bad shape rows=%lld ld=%d col0=%d ncols=%d", rows, ld, col0, ncols);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bg::masked_sqdiff_kernel, dim3(bg::MSE_BLOCKS), dim3(256), 0, s, pred, target, row_mask, rows, ld,
+                       col0, ncols, scratch);
+    hipLaunchKernelGGL(bg::masked_mse_final_kernel, dim3(1), dim3(256), 0, s, scratch, ncols, out3);
+    return bg::launch_status("bg_masked_mse");
+}
+
 extern "C" int bg_layernorm_split_fwd(const void* hi, const void* lo, const float* gamma, const float* beta, void* y,
                                       int dtype, int M, float eps, bg_stream_t stream) {
     BG_REQUIRE(hi && lo && gamma && beta && y, BG_E_ARG, "bg_layernorm_split_fwd: null pointer");

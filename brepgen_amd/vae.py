@@ -562,14 +562,28 @@ class AutoencoderKLFastEncode(_HipVAE):
     def forward(self, x, return_dict=True):
         if not x.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {x.device})")
-        dt = self._dtype()
         x_cl = x.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        return self._encode_cl(x_cl).permute(0, 3, 1, 2).contiguous()
+
+    def _encode_cl(self, x_cl):
+        """Channels-last point grids [F,32,32,3] -> channels-last latent modes [F,4,4,3]."""
+        dt = self._dtype()
         n, side = x_cl.shape[0], x_cl.shape[1]
         worst = side * side * 9 * self.block_out[0] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        out = torch.cat(outs) if len(outs) > 1 else outs[0]
-        return out.permute(0, 3, 1, 2).contiguous()
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def encode_tokens(self, surfPnt):
+        """Point grids [..., 32, 32, 3] (the datasets' layout) -> token-layout latents [..., 48]; equals trainer.py:519-524
+        `vae(p.flatten(0,1).permute(0,3,1,2)).unflatten(0,(B,-1)).flatten(-2,-1).permute(0,1,3,2).flatten(-2,-1)` without
+        the NCHW round trips."""
+        if not surfPnt.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {surfPnt.device})")
+        lead = surfPnt.shape[:-3]
+        x_cl = surfPnt.detach().to(torch.float32).reshape(-1, *surfPnt.shape[-3:]).contiguous()
+        z = self._encode_cl(x_cl)                                  # [F, 4, 4, latent]
+        return z.reshape(*lead, z.shape[1] * z.shape[2] * z.shape[3])
 
 
 class AutoencoderKL1DFastEncode(_HipVAE):
@@ -621,11 +635,24 @@ class AutoencoderKL1DFastEncode(_HipVAE):
     def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
         if not sample.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {sample.device})")
-        dt = self._dtype()
         x_cl = sample.detach().to(torch.float32).permute(0, 2, 1).contiguous()
+        return self._encode_cl(x_cl).permute(0, 2, 1).contiguous()
+
+    def _encode_cl(self, x_cl):
+        """Channels-last polylines [G,32,3] -> channels-last latent modes [G,4,3]."""
+        dt = self._dtype()
         n = x_cl.shape[0]
         worst = x_cl.shape[1] * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        out = torch.cat(outs) if len(outs) > 1 else outs[0]
-        return out.permute(0, 2, 1).contiguous()
+        return torch.cat(outs) if len(outs) > 1 else outs[0]
+
+    def encode_tokens(self, edgePnt):
+        """Polylines [..., 32, 3] -> token-layout latents [..., 12]; equals trainer.py:924-929
+        `vae(p.flatten(0,1).flatten(0,1).permute(0,2,1)) ... .permute(0,1,2,4,3).flatten(-2,-1)`."""
+        if not edgePnt.is_cuda:
+            raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {edgePnt.device})")
+        lead = edgePnt.shape[:-2]
+        x_cl = edgePnt.detach().to(torch.float32).reshape(-1, *edgePnt.shape[-2:]).contiguous()
+        z = self._encode_cl(x_cl)                                  # [G, 4, latent]
+        return z.reshape(*lead, z.shape[1] * z.shape[2])

@@ -272,6 +272,13 @@ int bg_add_noise(const float* x0, const float* noise, const float* sqrt_alpha_pr
                  const float* sqrt_one_minus_alpha_prod, float* out, int B, size_t per_sample,
                  bg_stream_t stream);
 
+/* Masked MSE of the trainers' loss / validation forward (trainer.py:354, 538, 597, 950-952; `loss_fn(pred[~mask],
+ * noise[~mask])`): pred / target fp32 [rows, ld], row_mask uint8 [rows] (1 = padded, skipped) or NULL, columns
+ * [col0, col0+ncols).  scratch: 1024 doubles.  out3 (device): {mean over valid elements, sum over valid rows of the
+ * per-row mean (the reduction of test_val, trainer.py:597), number of valid rows}.  Deterministic (no atomics). */
+int bg_masked_mse(const float* pred, const float* target, const uint8_t* row_mask, long long rows, int ld, int col0,
+                  int ncols, double* scratch, float* out3, bg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

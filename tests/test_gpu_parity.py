@@ -381,3 +381,62 @@ def test_per_sample_timesteps_training_style(pc):
         want = orc.surfz_forward(sd, z, t, pos, mask, cl)
         got = m(z.cuda(), t.cuda(), pos.cuda(), mask.cuda(), cl.cuda())
     assert float((got.cpu() - want)[~mask].abs().max()) < 1e-5
+
+
+# ---- training / validation forward (brepgen_amd/training.py) -------------------------------
+def test_masked_mse_matches_torch(pc):
+    from brepgen_amd import training
+    g = pc.gen(8)
+    pred, tgt = torch.randn(4, 60, 18, generator=g), torch.randn(4, 60, 18, generator=g)
+    mask = torch.rand(4, 60, generator=g) < 0.3
+    for m, cols in ((mask, None), (None, None), (mask, (0, 12)), (mask, (12, 18))):
+        r = training.masked_mse(pred.cuda(), tgt.cuda(), None if m is None else m.cuda(), cols)
+        sel = slice(None) if cols is None else slice(*cols)
+        a, b = (pred, tgt) if m is None else (pred[~m], tgt[~m])
+        a, b = a.reshape(-1, 18)[:, sel].double(), b.reshape(-1, 18)[:, sel].double()
+        assert abs(float(r["mean"]) - float(((a - b) ** 2).mean())) < 1e-6
+        assert abs(float(r["row_mean_sum"]) - float(((a - b) ** 2).mean(-1).sum())) < 1e-3
+        assert int(r["rows"]) == a.shape[0]
+    again = training.masked_mse(pred.cuda(), tgt.cuda(), mask.cuda())
+    assert float(again["mean"]) == float(training.masked_mse(pred.cuda(), tgt.cuda(), mask.cuda())["mean"])   # deterministic
+
+
+def test_encode_tokens_equal_the_trainer_permute_chains(pc):
+    import brepgen_amd as bga
+    from oracle import vae as ov
+    g = pc.gen(9)
+    se = bga.AutoencoderKLFastEncode(**pc.SURF_CFG)
+    se.load_state_dict(ov.seeded_state_dict(ov.surf_encoder_spec(), 51), strict=True)
+    ee = bga.AutoencoderKL1DFastEncode(**pc.EDGE_CFG)
+    ee.load_state_dict(ov.seeded_state_dict(ov.edge_encoder_spec(), 61), strict=True)
+    se, ee = se.cuda().eval(), ee.cuda().eval()
+    surfPnt = torch.randn(2, 3, 32, 32, 3, generator=g).cuda()
+    edgePnt = torch.randn(2, 3, 4, 32, 3, generator=g).cuda()
+    with torch.no_grad():
+        z = se(surfPnt.flatten(0, 1).permute(0, 3, 1, 2))                                            # trainer.py:519-524
+        want = z.unflatten(0, (2, -1)).flatten(-2, -1).permute(0, 1, 3, 2).flatten(-2, -1)
+        assert torch.equal(se.encode_tokens(surfPnt), want)
+        z = ee(edgePnt.flatten(0, 1).flatten(0, 1).permute(0, 2, 1))                                 # trainer.py:924-929
+        want = z.unflatten(0, (-1, 4)).unflatten(0, (2, -1)).permute(0, 1, 2, 4, 3).flatten(-2, -1)
+        assert torch.equal(ee.encode_tokens(edgePnt), want)
+
+
+def test_ldm_loss_vs_oracle_pipeline(pc):
+    """add_noise (per-sample t) -> SurfZNet -> masked MSE against the same three steps done by the CPU oracle."""
+    import brepgen_amd as bga
+    from brepgen_amd import training
+    from oracle.schedulers import OracleDDPM
+    m, sd = pc.build_net("SurfZNet", 41, False, F32)
+    z, _, pos, mask, _ = pc.synth_inputs("SurfZNet", 4, 30, 1, False)
+    g = pc.gen(10)
+    noise = torch.randn(z.shape, generator=g)
+    t = torch.tensor([9, 49, 199, 499])
+    ddpm = bga.DDPMScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
+                             beta_start=0.0001, beta_end=0.02, clip_sample=False)
+    got = training.ldm_loss(m, ddpm, z.cuda(), t.cuda(), noise.cuda(), (pos.cuda(),), mask.cuda())
+    x_t = OracleDDPM().add_noise(z, noise, t)
+    pred = pc.orc.surfz_forward(sd, x_t, t, pos, mask)
+    want = ((pred[~mask] - noise[~mask]) ** 2).mean()
+    assert abs(float(got["mean"]) - float(want)) < 1e-5 * max(1.0, float(want))
+    vals = training.validation_losses(m, ddpm, z.cuda(), (pos.cuda(),), mask.cuda(), generator=pc.gen(11))
+    assert len(vals) == 5 and all(torch.isfinite(v["mean"]) for v in vals)
