@@ -3,6 +3,11 @@
 // the path's FLOPs.  MFMA-bound.
 //
 //   out[m,n] = act(sum_k a[m,k] * w[n,k] + bias[n]) (+ add[(m / add_div), n] (+ add2[...]))   a, w 16-bit; fp32 accumulate
+// plus, for the 16-bit modes of the denoisers:
+//   * LayerNorm fold (consumer): a = raw residual rows, w = T(gamma * W); the epilogue applies per-row (rstd, -mean*rstd)
+//     summed from per-64-column (sum, sum of squares) partials a producer GEMM left behind;
+//   * split residual (producer): the fp32 result + residual is stored as two 16-bit planes hi = T(v), lo = T(v - hi),
+//     hi being the next GEMM's A operand, together with those partials.
 //
 // Design (gfx950):
 //   * tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), v_mfma_f32_32x32x16_{bf16,f16}: 16 fp32 accumulators per
@@ -18,8 +23,9 @@
 //   * fragment reads are software-pipelined one k-slice ahead of the MFMAs (order pinned with sched_barrier);
 //   * shipped kernel = the PERSISTENT one (gemm16_persistent_kernel): 2 workgroups per CU stay resident and walk
 //     the tile list, the DMA stream runs across tile seams, the epilogue works out of a small wave-private LDS patch
-//     that does not alias the ring, bias / ReLU / fp32-residual / broadcast adds fused, full-line global stores;
-//   * XCD-aware tile order: workgroups that run concurrently on one XCD take consecutive tiles (shared A row panel).
+//     that does not alias the ring, everything it needs from memory (bias / column sums, residual rows, row statistics)
+//     is requested at the start of the tile's last K-step, full-line global stores;
+//   * XCD-aware tile order: XCD x walks row panels x, x + 8, ... column-fastest (shared A row panels per L2).
 // The exploration behind this shape (3-stage rings, 256-row tiles, register epilogue, loader/consumer wave
 // specialisation, ablations) is summarised in DESIGN.md section 4 with the logs under profiles/r01/; those kernel
 // variants live in the git history (commit "Persistent 128x128 GEMM ...").
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   16-bit output: neighbouring lanes swap one accumulator so each lane owns a bf16 pair, the patch holds a
 //   32 x 64 bf16 slab (128-byte rows) -> 16-byte-per-lane, full-line global stores.
 //   fp32 output / residual: 32 x 32 fp32 slab per MFMA tile -> 128-byte row segments, residual added in flight.
+//   split output: 16 x 64 fp32 slab -> a lane owns 8 columns of a row: hi / lo / residual as 16-byte accesses.
 // ------------------------------------------------------------------------------------------------------
 // MODE selects the epilogue (one instantiation each, so that no instantiation carries the registers of another):
 //   P_PLAIN16  16-bit output, bias (+ReLU)                              -- QKV / FFN1 without the LayerNorm fold, VAE convs

@@ -6,9 +6,12 @@ Same constructor / ``forward`` signatures and the same checkpoint key layout as 
 ``nn.Module`` tree below only *holds* the fp32 parameters.
 
 Precision: like the reference, the module follows autocast -- inside ``torch.autocast('cuda')`` (as sample.py:121
-runs it) GEMM/attention operands are bf16 with fp32 accumulation, an fp32 residual stream and fp32 LayerNorm /
-softmax statistics; outside autocast everything is exact fp32 (f32-input MFMA).  ``compute_dtype`` overrides.
-The returned eps is always fp32.
+runs it) GEMM/attention operands are 16-bit (the autocast dtype: fp16 by default, bf16 if asked) with fp32
+accumulation and fp32 LayerNorm / softmax statistics; the residual stream is kept as a (hi, lo) pair of 16-bit planes
+(~16 mantissa bits) whose hi plane feeds the next GEMM directly, norm1 / norm2 are folded into the QKV / FFN1 GEMM
+epilogues (``fold_layernorm``; False restores an fp32 stream and LayerNorm kernels), and the first Linear + LayerNorm +
+SiLU of every input embed is one kernel (``fuse_embed``).  Outside autocast everything is exact fp32 (f32-input
+MFMA).  ``compute_dtype`` overrides.  The returned eps is always fp32.
 """
 import ctypes as C
 
