@@ -74,6 +74,11 @@ _SIGNATURES = {
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_denoiser_fwd": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenoiserInputs), fp, vp, C.c_size_t, vp]),
+    "bg_embed_mlp_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "bg_embed_mlp_fwd": (C.c_int, [C.POINTER(MlpWeights), C.c_int, vp, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int,
+                                   vp, C.c_size_t, vp]),
+    "bg_encoder_layer_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "bg_encoder_layer_fwd": (C.c_int, [C.POINTER(LayerWeights), C.c_int, fp, u8p, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "bg_cfg_ddpm_step": (C.c_int, [fp, fp, C.c_float, fp, fp, fp, C.c_size_t] + [C.c_float] * 6 + [vp]),
     "bg_pndm_step": (C.c_int, [fp, fp, C.c_float, fp, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, fp,

@@ -321,6 +321,68 @@ extern "C" size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype) {
     return bg::plan(net, B, S, E, dtype).total;
 }
 
+// ---- stand-alone pieces of the whole-net call (same code paths, caller-owned scratch) ---------------------------------
+extern "C" size_t bg_embed_mlp_scratch_bytes(int rows, int dtype) {
+    if (rows <= 0) return 0;
+    const size_t es = (dtype == BG_F32) ? 4 : 2;
+    return bg::align_up((size_t)rows * 768 * es) + bg::align_up((size_t)rows * 768 * 4);
+}
+
+extern "C" int bg_embed_mlp_fwd(const bg_mlp_weights* m, int dtype, const void* x, int lda, int rows, float* out, int ldc,
+                                const float* add, int ld_add, int add_div, void* scratch, size_t scratch_bytes,
+                                bg_stream_t stream) {
+    using namespace bg;
+    BG_REQUIRE(m && x && out && scratch, BG_E_ARG, "bg_embed_mlp_fwd: null pointer");
+    BG_REQUIRE(dtype == BG_F32 || dtype == BG_BF16 || dtype == BG_F16, BG_E_DTYPE, "bg_embed_mlp_fwd: dtype %d", dtype);
+    BG_REQUIRE(rows > 0 && lda >= m->k_in && ldc >= m->n_out, BG_E_SHAPE, "bg_embed_mlp_fwd: bad shape");
+    BG_REQUIRE(scratch_bytes >= bg_embed_mlp_scratch_bytes(rows, dtype), BG_E_WORKSPACE, "bg_embed_mlp_fwd: scratch too small");
+    BG_REQUIRE(((uintptr_t)scratch & 255) == 0, BG_E_ALIGN, "bg_embed_mlp_fwd: scratch must be 256-byte aligned");
+    bg_denoiser_weights none{};
+    Ctx c;
+    c.w = &none; c.s = (hipStream_t)stream; c.dtype = dtype; c.ws = reinterpret_cast<unsigned char*>(scratch);
+    c.X = nullptr;
+    c.H = c.ws;
+    c.R = c.ws + align_up((size_t)rows * 768 * ((dtype == BG_F32) ? 4 : 2));
+    return embed_mlp(c, *m, x, lda, rows, out, ldc, add, ld_add, add ? add_div : 1, nullptr, 0, 1);
+}
+
+extern "C" size_t bg_encoder_layer_scratch_bytes(int B, int N, int dtype) {
+    if (B <= 0 || N <= 0) return 0;
+    const size_t es = (dtype == BG_F32) ? 4 : 2, M = (size_t)B * N;
+    return bg::align_up(M * 768 * es) + bg::align_up(M * 2304 * es);
+}
+
+// One pre-LN encoder layer (nn.TransformerEncoderLayer(norm_first=True), network.py:1076-1078) on an fp32 residual
+// stream x [B*N, 768], in place -- the unfolded formulation: LayerNorm kernels + unfolded weights (qkv_colsum == NULL).
+extern "C" int bg_encoder_layer_fwd(const bg_layer_weights* L, int dtype, float* x, const uint8_t* key_pad, int B, int N,
+                                    void* scratch, size_t scratch_bytes, bg_stream_t stream) {
+    using namespace bg;
+    BG_REQUIRE(L && x && scratch, BG_E_ARG, "bg_encoder_layer_fwd: null pointer");
+    BG_REQUIRE(dtype == BG_F32 || dtype == BG_BF16 || dtype == BG_F16, BG_E_DTYPE, "bg_encoder_layer_fwd: dtype %d", dtype);
+    BG_REQUIRE(B > 0 && N > 0, BG_E_SHAPE, "bg_encoder_layer_fwd: empty shape");
+    BG_REQUIRE(L->qkv_colsum == nullptr && L->w1_colsum == nullptr && L->ln1_g && L->ln2_g, BG_E_ARG,
+               "bg_encoder_layer_fwd: takes unfolded weights (the LayerNorm-folded layers run inside bg_denoiser_fwd)");
+    BG_REQUIRE(scratch_bytes >= bg_encoder_layer_scratch_bytes(B, N, dtype), BG_E_WORKSPACE, "bg_encoder_layer_fwd: scratch too small");
+    BG_REQUIRE(((uintptr_t)scratch & 255) == 0, BG_E_ALIGN, "bg_encoder_layer_fwd: scratch must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int M = B * N;
+    unsigned char* ws = reinterpret_cast<unsigned char*>(scratch);
+    void* H = ws;
+    void* R = ws + align_up((size_t)M * 768 * ((dtype == BG_F32) ? 4 : 2));
+    int rc;
+    if ((rc = layernorm768(x, L->ln1_g, L->ln1_b, H, dtype, M, 1e-5f, 0, s))) return rc;
+    GemmArgs qkv{H, 768, L->w_qkv, L->b_qkv, R, 2304, M, 2304, 2304, 768, dtype, BG_ACT_NONE, nullptr, 0, 1};
+    if ((rc = gemm(qkv, dtype, s))) return rc;
+    if ((rc = attention(R, key_pad, H, B, N, dtype, s))) return rc;
+    GemmArgs op{H, 768, L->w_o, L->b_o, x, 768, M, 768, 768, 768, BG_F32, BG_ACT_NONE, x, 768, 1};
+    if ((rc = gemm(op, dtype, s))) return rc;
+    if ((rc = layernorm768(x, L->ln2_g, L->ln2_b, H, dtype, M, 1e-5f, 0, s))) return rc;
+    GemmArgs f1{H, 768, L->w_1, L->b_1, R, 1024, M, 1024, 1024, 768, dtype, BG_ACT_RELU, nullptr, 0, 1};
+    if ((rc = gemm(f1, dtype, s))) return rc;
+    GemmArgs f2{R, 1024, L->w_2, L->b_2, x, 768, M, 768, 768, 1024, BG_F32, BG_ACT_NONE, x, 768, 1};
+    return gemm(f2, dtype, s);
+}
+
 extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
                                void* workspace, size_t workspace_bytes, bg_stream_t stream) {
     BG_REQUIRE(w && in, BG_E_ARG, "bg_denoiser_fwd: null descriptor");

@@ -123,6 +123,40 @@ def embed_ln_silu(x, k, w0, b0, gamma, beta, out_dtype=torch.float32, eps=1e-5):
     return out
 
 
+def embed_mlp(mlp_weights, dtype, x, k=None, add=None, add_div=1):
+    """bg_embed_mlp_fwd on one packed bg_mlp_weights (e.g. net._pack(dt)[0].embed[i]); x [rows, lda]; -> fp32 [rows, n_out]."""
+    import ctypes as C
+    _need_cuda(x, add)
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, lda = x.shape[0], x.stride(0)
+    out = torch.empty(rows, mlp_weights.n_out, device=x.device, dtype=torch.float32)
+    nbytes = _lib.load().bg_embed_mlp_scratch_bytes(rows, bg_dtype(dtype))
+    scratch = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    check(_lib.load().bg_embed_mlp_fwd(C.byref(mlp_weights), bg_dtype(dtype), x.data_ptr(), lda, rows, ptr(out), out.shape[1],
+                                       ptr(add), add.shape[-1] if add is not None else 0, add_div, base, nbytes, stream()),
+          "bg_embed_mlp_fwd")
+    return out
+
+
+def encoder_layer(layer_weights, dtype, x, key_pad, B, N):
+    """bg_encoder_layer_fwd: one pre-LN encoder layer on the fp32 stream x [B*N, 768]; returns the updated copy."""
+    import ctypes as C
+    _need_cuda(x, key_pad)
+    assert x.dtype == torch.float32 and x.shape == (B * N, 768)
+    x = x.contiguous().clone()
+    kp = None
+    if key_pad is not None:
+        kp = key_pad.contiguous()
+        kp = kp.view(torch.uint8) if kp.dtype == torch.bool else kp.to(torch.uint8)
+    nbytes = _lib.load().bg_encoder_layer_scratch_bytes(B, N, bg_dtype(dtype))
+    scratch = torch.empty(nbytes + 256, device=x.device, dtype=torch.uint8)
+    base = (scratch.data_ptr() + 255) // 256 * 256
+    check(_lib.load().bg_encoder_layer_fwd(C.byref(layer_weights), bg_dtype(dtype), ptr(x), ptr(kp), B, N, base, nbytes,
+                                           stream()), "bg_encoder_layer_fwd")
+    return x
+
+
 def attention(qkv, key_pad, B, N):
     """qkv [B*N, 2304] (q pre-scaled by 1/8), key_pad bool/uint8 [B,N] or None -> [B*N, 768]."""
     _need_cuda(qkv, key_pad)

@@ -182,6 +182,20 @@ size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype);
 int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
                     void* workspace, size_t workspace_bytes, bg_stream_t stream);
 
+/* Pieces of the whole-net call on their own (same kernels, caller-owned 256-byte-aligned scratch):
+ *   bg_embed_mlp_fwd      Linear(k,768) -> LayerNorm -> SiLU -> Linear(768,n) (+ add[m / add_div]) of one bg_mlp_weights
+ *                         (network.py:1080-1099); x fp32 rows (input embeds) or `dtype` rows (fc_out); out fp32.
+ *   bg_encoder_layer_fwd  one nn.TransformerEncoderLayer(768, 12, norm_first=True, dim_feedforward=1024) (network.py:
+ *                         1076-1078) on an fp32 residual stream x [B*N,768], in place; key_pad uint8 [B,N] or NULL.  Takes
+ *                         UNFOLDED layer weights (qkv_colsum == w1_colsum == NULL): the LayerNorm-folded, split-residual
+ *                         formulation of the 16-bit modes keeps state between layers and lives inside bg_denoiser_fwd. */
+size_t bg_embed_mlp_scratch_bytes(int rows, int dtype);
+int bg_embed_mlp_fwd(const bg_mlp_weights* m, int dtype, const void* x, int lda, int rows, float* out, int ldc,
+                     const float* add, int ld_add, int add_div, void* scratch, size_t scratch_bytes, bg_stream_t stream);
+size_t bg_encoder_layer_scratch_bytes(int B, int N, int dtype);
+int bg_encoder_layer_fwd(const bg_layer_weights* L, int dtype, float* x, const uint8_t* key_pad, int B, int N,
+                         void* scratch, size_t scratch_bytes, bg_stream_t stream);
+
 /* ---- scheduler steps (diffusers==0.27 arithmetic, called at sample.py:137,153,202,222,236,282) */
 
 /* DDPMScheduler.step fused with the classifier-free-guidance combine (sample.py:132-134):

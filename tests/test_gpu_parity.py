@@ -440,3 +440,29 @@ def test_ldm_loss_vs_oracle_pipeline(pc):
     assert abs(float(got["mean"]) - float(want)) < 1e-5 * max(1.0, float(want))
     vals = training.validation_losses(m, ddpm, z.cuda(), (pos.cuda(),), mask.cuda(), generator=pc.gen(11))
     assert len(vals) == 5 and all(torch.isfinite(v["mean"]) for v in vals)
+
+
+# ---- stand-alone entry points named by SURVEY.md section 8(b): bg_embed_mlp_fwd, bg_encoder_layer_fwd ---------------------
+@pytest.mark.parametrize("dtype,tol", [(F32, 1e-5), (BF16, 3e-2), (F16, 4e-3)])
+def test_encoder_layer_and_embed_mlp_entry_points(pc, dtype, tol):
+    m, sd = pc.build_net("SurfZNet", 13, False, dtype)
+    m.fold_layernorm = False                       # the stand-alone layer takes unfolded weights + an fp32 stream
+    w, _keep = m._pack(dtype)
+    g = pc.gen(12)
+    B, N = 3, 41
+    x = torch.randn(B, N, 768, generator=g)
+    key_pad = torch.zeros(B, N, dtype=torch.bool)
+    key_pad[0, 30:] = True
+    key_pad[2, 5:] = True
+    got = pc.ops.encoder_layer(w.layers[2], dtype, x.reshape(B * N, 768).cuda(), key_pad.cuda(), B, N).cpu().reshape(B, N, 768)
+    want = pc.orc.encoder_layer(sd, 2, x, key_pad)
+    assert float((got - want)[~key_pad].abs().max()) < tol * max(1.0, float(want.abs().max()))
+    z = torch.randn(50, 48, generator=g)
+    got = pc.ops.embed_mlp(w.embed[0], dtype, z.cuda()).cpu()                     # z_embed: 48 -> 768 -> 768
+    want = pc.orc.embed_mlp(sd, "z_embed", z)
+    assert float((got - want).abs().max()) < tol * max(1.0, float(want.abs().max()))
+    m.fold_layernorm = True
+    wf, _ = m._pack(dtype)
+    if dtype != F32:                               # folded weights are refused with an explanation
+        with pytest.raises(Exception, match="unfolded"):
+            pc.ops.encoder_layer(wf.layers[2], dtype, x.reshape(B * N, 768).cuda(), None, B, N)
