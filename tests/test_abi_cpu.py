@@ -108,6 +108,17 @@ def test_no_cpu_fallback():
         s.step(torch.zeros(2, 3), 5, torch.zeros(2, 3))
 
 
+def test_training_and_pipeline_helpers_have_no_cpu_fallback_either():
+    from brepgen_amd import training
+    with pytest.raises(_lib.BrepgenHipError):
+        training.masked_mse(torch.zeros(2, 3, 6), torch.zeros(2, 3, 6))
+    enc = bga.AutoencoderKL1DFastEncode(in_channels=3, out_channels=3, down_block_types=["DownBlock1D"] * 3,
+                                        up_block_types=["UpBlock1D"] * 3, block_out_channels=[128, 256, 512],
+                                        layers_per_block=2, act_fn="silu", latent_channels=3, norm_num_groups=32, sample_size=512)
+    with pytest.raises(_lib.BrepgenHipError):
+        enc.encode_tokens(torch.zeros(1, 2, 32, 3))
+
+
 def test_scheduler_host_logic_matches_oracle():
     d, o = bga.DDPMScheduler(clip_sample=True, clip_sample_range=3), OracleDDPM(clip_sample_range=3)
     for n in (1000, 50):
