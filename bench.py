@@ -193,7 +193,9 @@ def main():
                        "sample_steps_per_s": round(steps_per_s * B_PER_GPU, 1),
                        "algorithmic_tflop_per_step": round(f_step / 1e12, 3),
                        "model_tflops_per_gpu": round(f_step * args.steps / elapsed / 1e12, 1),
-                       "finite": finite, "parallelism": f"batch-sharded x{world}, 1 all_gather of latents"},
+                       "finite": finite, "parallelism": f"batch-sharded x{world}, 1 all_gather of latents",
+                       "formulation": "norm1/norm2 folded into the QKV/FFN1 GEMM epilogues, residual stream as (hi, lo) "
+                                      "16-bit planes, fused input embeds; conditioning cache off (every embed recomputed)"},
             "roofline": roofline, "kernels": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
