@@ -1,0 +1,87 @@
+"""CPU emulation of the 16-bit formulation the HIP path runs: LayerNorm folded into the QKV / FFN1
+GEMMs + residual stream as (hi, lo) 16-bit planes, against the un-folded 16-bit pipeline and the fp32 reference
+golden vectors.  Pure torch on the CPU: it pins the *algebra and the rounding points* (gamma*W rounded once, column sums
+of the rounded matrix, statistics of the fp32 stream, hi = T(x) as GEMM operand) independently of any kernel, and
+backs the claim that the fold costs no accuracy.  The device implementation is checked against the same golden vectors
+in tests/test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoisers as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+D = 768
+
+
+def emulate(sd, z, t, pos, mask, T, fold):
+    r = lambda x: x.to(T).to(torch.float32)                                  # one rounding to the operand dtype
+
+    def mlp(p, x, lowk=True):
+        h = x @ sd[p + ".0.weight"].t() + sd[p + ".0.bias"] if lowk else r(x) @ r(sd[p + ".0.weight"]).t() + sd[p + ".0.bias"]
+        h = r(orc.silu(orc.layer_norm(h, sd[p + ".1.weight"], sd[p + ".1.bias"])))
+        return h @ r(sd[p + ".3.weight"]).t() + sd[p + ".3.bias"]
+
+    B, N, _ = z.shape
+
+    def attn(qkv):
+        q, k, v = qkv.split(D, -1)
+        hd = lambda u: u.reshape(B, N, 12, 64).permute(0, 2, 1, 3)
+        q, k, v = hd(q), hd(k), hd(v)
+        s = (q @ k.transpose(-1, -2)).masked_fill(mask.reshape(B, 1, 1, N), float("-inf"))
+        s = s - s.max(-1, keepdim=True).values
+        e = torch.exp(s)
+        o = (r(e) @ v) / e.sum(-1, keepdim=True)
+        return r(o.permute(0, 2, 1, 3).reshape(B, N, D))
+
+    def lin_ln(x, hi, g, b, W, bias):
+        if not fold:
+            return r(orc.layer_norm(x, g, b)) @ r(W).t() + bias
+        Wp = r(W * g[None, :])                                               # T(gamma * W), rounded once at pack time
+        colsum, c = Wp.sum(1), bias + W @ b
+        S, Q = x.sum(-1, keepdim=True), (x * x).sum(-1, keepdim=True)
+        mean = S / D
+        rstd = torch.rsqrt((Q / D - mean * mean).clamp(min=0) + 1e-5)
+        return rstd * (hi @ Wp.t()) - (mean * rstd) * colsum[None, None, :] + c
+
+    split = lambda x: (r(x), r(x - r(x)))
+    x = mlp("z_embed", z) + mlp("p_embed", pos) + mlp("time_embed", orc.sincos_embedding(t), lowk=False).unsqueeze(1)
+    hi, lo = split(x)
+    for li in range(12):
+        p = f"net.layers.{li}."
+        Wi, bi = sd[p + "self_attn.in_proj_weight"].clone(), sd[p + "self_attn.in_proj_bias"].clone()
+        Wi[:D] *= 0.125
+        bi[:D] *= 0.125
+        xx = hi + lo if fold else x
+        qkv = r(lin_ln(xx, hi, sd[p + "norm1.weight"], sd[p + "norm1.bias"], Wi, bi))
+        xn = xx + (attn(qkv) @ r(sd[p + "self_attn.out_proj.weight"]).t() + sd[p + "self_attn.out_proj.bias"])
+        hi, lo = split(xn)
+        xx = hi + lo if fold else xn
+        f = r(torch.relu(lin_ln(xx, hi, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "linear1.weight"], sd[p + "linear1.bias"])))
+        xn = xx + (f @ r(sd[p + "linear2.weight"]).t() + sd[p + "linear2.bias"])
+        hi, lo = split(xn)
+        x = hi + lo if fold else xn
+    h = r(orc.layer_norm(x, sd["net.norm.weight"], sd["net.norm.bias"]))
+    h = h @ r(sd["fc_out.0.weight"]).t() + sd["fc_out.0.bias"]
+    h = r(orc.silu(orc.layer_norm(h, sd["fc_out.1.weight"], sd["fc_out.1.bias"])))
+    return h @ r(sd["fc_out.3.weight"]).t() + sd["fc_out.3.bias"]
+
+
+@pytest.mark.parametrize("T,bound", [(torch.bfloat16, 4e-2), (torch.float16, 8e-3)])
+def test_fold_and_split_residual_cost_no_accuracy(T, bound):
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    meta = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))["cases"]["surfz_b3_n60"]
+    g = np.load(os.path.join(GOLDEN, "surfz_b3_n60.npz"))
+    sd = orc.seeded_state_dict(meta["net"], meta["weight_seed"], meta["use_cf"])
+    a = {k: torch.from_numpy(g[k]) for k in g.files}
+    want, valid = a["out"], ~a["surf_mask"]
+    with torch.no_grad():
+        e = {}
+        for fold in (False, True):
+            got = emulate(sd, a["surfZ"], a["timesteps"], a["surfPos"], a["surf_mask"], T, fold)
+            e[fold] = float((got - want)[valid].abs().max()), float((got - want)[valid].abs().mean())
+    assert e[True][0] < bound and e[False][0] < bound                       # the bounds the GPU tests assert
+    assert e[True][0] < 1.25 * e[False][0] and e[True][1] < 1.25 * e[False][1], e
