@@ -286,6 +286,16 @@ int bg_add_noise(const float* x0, const float* noise, const float* sqrt_alpha_pr
                  const float* sqrt_one_minus_alpha_prod, float* out, int B, size_t per_sample,
                  bg_stream_t stream);
 
+/* Device loop of joint_optimize (utils.py:746-772): per-face 3-D offsets fitted with `iters` AdamW steps (torch.optim.AdamW
+ * arithmetic; the reference uses lr 1e-3, betas (0.95, 0.999), weight_decay 1e-6, eps 1e-8, 200 iterations) on
+ *   L = mean_f sum_{e in edges_f} min_{s in surf_f} |e - (s + off_f)|^2        (chamferdist ChamferDistance(reverse=True)).
+ * surf [F,P,3] (P <= 4096), edge_pts [edge_off[F],3] with face f owning rows edge_off[f] .. edge_off[f+1]-1 (int32, device).
+ * offsets_out [F,3] and surf_out [F,P,3] (optional) are those of the LAST evaluated iteration (what the reference returns,
+ * utils.py:770); loss_out [F] (optional) the per-face Chamfer sums of that iteration.  One launch, deterministic. */
+int bg_chamfer_offset_fit(const float* surf, const float* edge_pts, const int* edge_off, int F, int P, int iters, double lr,
+                          double beta1, double beta2, double weight_decay, double eps, float* offsets_out, float* surf_out,
+                          float* loss_out, bg_stream_t stream);
+
 /* Masked MSE of the trainers' loss / validation forward (trainer.py:354, 538, 597, 950-952; `loss_fn(pred[~mask],
  * noise[~mask])`): pred / target fp32 [rows, ld], row_mask uint8 [rows] (1 = padded, skipped) or NULL, columns
  * [col0, col0+ncols).  scratch: 1024 doubles.  out3 (device): {mean over valid elements, sum over valid rows of the
