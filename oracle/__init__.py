@@ -16,4 +16,10 @@ Pinning status
   offline.  The restatement follows the published 0.27 algorithm and the
   reference's call sites (``sample.py:101-117,128-153``); it is checked by
   self-consistency tests and the known-answer constants in SURVEY.md App. B.4.
+* ``oracle.vae`` — PARITY UNPINNED for the same reason (the decoder / encoder blocks are diffusers code); restated from
+  the published 0.27 blocks, anchored on the reference's wiring (``network.py:30-299``) and on the parameter counts
+  SURVEY.md App. C records (asserted in ``tests/test_oracle_vae.py``).
+* ``oracle.joint_opt`` — the Chamfer offset fit of ``utils.py:746-772``: loss semantics PARITY UNPINNED (``chamferdist``,
+  unversioned third-party CUDA package), optimiser + gradient PINNED against ``torch.optim.AdamW`` + autograd
+  (``tests/test_oracle_joint_opt.py``).
 """
