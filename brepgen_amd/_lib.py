@@ -95,6 +95,7 @@ _SIGNATURES = {
     "bg_tune_set": (C.c_int, [C.c_int, C.c_int]),
     "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
     "bg_chamfer_offset_fit": (C.c_int, [fp, fp, vp, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5 + [fp, fp, fp, vp]),
+    "bg_philox_randn": (C.c_int, [fp, C.c_longlong, C.c_int, C.c_ulonglong, C.c_uint, C.c_longlong, C.c_int, vp]),
     "bg_masked_mse": (C.c_int, [fp, fp, u8p, C.c_longlong, C.c_int, C.c_int, C.c_int, vp, fp, vp]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -430,11 +430,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     int m0, n0;
     unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0;
     if (INSTR) t_begin = __builtin_amdgcn_s_memtime();
-    if (!tile_at(w_local, m0, n0)) return;
+    // walk 2 (A/B knob): workgroups w and w + cnt/2 of an XCD -- observed to share a CU (tools/cu_census.hip) -- take
+    // ADJACENT column tiles of one row panel, so the partner's A lines are already in the CU's vector L1
+    const int t_first = (walk == 2 && (cnt & 1) == 0) ? ((w_local % (cnt >> 1)) << 1) + (w_local / (cnt >> 1)) : w_local;
+    if (!tile_at(t_first, m0, n0)) return;
     set_src(m0, n0);
     issue(0, 0);
     int slot = 0;
-    for (int t = w_local;; t += cnt) {
+    for (int t = t_first;; t += cnt) {
         const int cm0 = m0, cn0 = n0;                             // coordinates of the tile being computed
         const bool has_next = tile_at(t + cnt, m0, n0);           // (m0, n0) now name the NEXT tile
         f32x16 acc[TM][TN];

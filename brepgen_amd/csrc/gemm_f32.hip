@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// M <= 8 (the time-embedding MLP: one row per distinct timestep, usually 1): a 64x64-tile GEMM would run 12 blocks
+// M == 1 (the time-embedding MLP of a sampling step: ONE timestep shared by the batch): a 64x64-tile GEMM would run 12 blocks
 // through a 48-step latency chain.  Here one wave owns one output column: lanes stride over K (coalesced 256-byte
 // reads of the weight row), fma-accumulate, butterfly-reduce.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(GemmArgs g) {
@@ -106,7 +106,10 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         set_error("gemm_f32: split residual / LayerNorm fold exist for 16-bit operands only");
         return BG_E_DTYPE;
     }
-    if (g.gemv_ok && g.M <= 8 && g.K >= 64) {
+    // Dispatch rule: the GEMV rounds differently from the MFMA's k-ordered chain, so it may only be chosen by something
+    // that does not depend on the batch composition.  M == 1 <=> one shared timestep (n_timesteps == 1) for ANY batch size;
+    // per-sample timesteps (M == B) always take the MFMA kernel, so a sample gives the same bits in every batch.
+    if (g.gemv_ok && g.M == 1 && g.K >= 64) {
         ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K, 4.0 * g.N * (double)g.K, s);
         hipLaunchKernelGGL(gemv_f32_kernel, dim3((g.N + 3) / 4), dim3(256), 0, s, g);
         return launch_status("gemv_f32");

@@ -237,7 +237,11 @@ class _HipDenoiser(nn.Module):
         inp.mask, inp.timesteps, inp.class_label = ptr(mk), ptr(t), ptr(class_label)
         # step-invariant conditioning cache, keyed on the identity + version of the conditioning tensors
         inp.cond_cache, inp.cond_cache_valid = None, 0
-        if self.cache_conditioning and surf_pos is not None and not self.training:
+        # (never while a HIP graph is being captured: the flag would be baked into the graph, and a replay after the
+        #  caller refreshed the static conditioning buffers through raw pointers would use stale embeds)
+        use_cache = (self.cache_conditioning and surf_pos is not None and not self.training
+                     and not torch.cuda.is_current_stream_capturing())
+        if use_cache:
             # The cache entry holds references to the tensors it was computed from: their storage cannot be
             # recycled for other data while cached, so object identity + in-place version is a sound key.
             conds = [c for c in (surf_pos, surf_z) if c is not None]
@@ -250,13 +254,14 @@ class _HipDenoiser(nn.Module):
                               "buf": torch.empty(B * S, D, device=dev, dtype=torch.float32)}
             inp.cond_cache = ptr(self._cond["buf"])
             inp.cond_cache_valid = int(self._cond["valid"])
-            self._cond["valid"] = True
         out = torch.empty(out_shape, device=dev, dtype=torch.float32)
         lib = _lib.load()
         nbytes = lib.bg_workspace_bytes(self.NET, B, S, E, w.dtype)
         ws = self._ws(nbytes, dev)
         check(lib.bg_denoiser_fwd(C.byref(w), C.byref(inp), ptr(out), ptr(ws), ws.numel(), stream()),
               f"bg_denoiser_fwd[{type(self).__name__}]")
+        if use_cache:
+            self._cond["valid"] = True               # only once the call that fills the cache has been enqueued
         return out
 
 

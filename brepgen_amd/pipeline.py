@@ -92,11 +92,17 @@ def build(eval_args, device="cuda", dist=None, autocast=torch.float16, weight_ro
 
 @torch.no_grad()
 def sample_batch(sampler, surf_vae, edge_vae, eval_args, generator=None, batch_size=None, **schedule):
-    """One pass of sample.py:120-299: latents for the whole batch on every rank + decoded point grids, as numpy arrays
-    named like the locals of sample.py (bbox values already divided by 3 as at sample.py:297-299)."""
+    """One pass of sample.py:120-299: latents + decoded point grids for the whole batch on every rank, as numpy arrays
+    named like the locals of sample.py (bbox values already divided by 3 as at sample.py:297-299).
+
+    Sharded run: each rank denoises AND VAE-decodes only its own samples (the decode is per face / per edge, SURVEY
+    8(e)); the latents and the decoded grids then travel in the ONE all_gather of the path."""
+    from .sampling import gather_latents
     B = batch_size or eval_args["batch_size"]
-    lat = sampler.sample(B, eval_args["num_surfaces"], eval_args["num_edges"], generator=generator, **schedule)
-    dec = decode_latents(surf_vae, edge_vae, lat)
+    lat = sampler.sample(B, eval_args["num_surfaces"], eval_args["num_edges"], generator=generator, gather=False,
+                         **schedule)
+    dec = decode_latents(surf_vae, edge_vae, lat)                    # this rank's rows only
+    dec = gather_latents(dec, sampler.dist, batch_size=B)
     host = lambda t: t.detach().float().cpu().numpy()
     return {"surfPos": host(dec["surfPos"]) / 3.0, "surfMask": dec["surfMask"].cpu().numpy(), "surfZ": host(dec["surfZ"]),
             "edge_pos": host(dec["edgePos"]) / 3.0, "edge_mask": dec["edgeM"].cpu().numpy(),

@@ -1,17 +1,22 @@
 """The denoising cascade of sample.py:120-286 on the HIP path, batch-sharded across the GPUs of one node.
 
 Stages (reference lines):  surfPos: PNDM[:158] -> late doubling -> DDPM[-250:]   (sample.py:126-153)
-                           bbox de-dup on the host                               (sample.py:159-183)
+                           bbox de-dup (on the device here)                      (sample.py:159-183)
                            surfZ:  PNDM x209                                     (sample.py:189-202)
                            edgePos: PNDM[:158] -> DDPM[-250:]                    (sample.py:208-236)
-                           edge de-dup on the host                               (sample.py:242-261)
+                           edge de-dup (on the device here)                      (sample.py:242-261)
                            edgeZV: PNDM x209, zero removed                       (sample.py:267-286)
 
-Multi-GPU: every op of the path is per-sample, so the batch is cut into contiguous per-rank slices
-(`shard_range`), the initial / ancestral noise for the WHOLE batch is drawn once from one seeded CPU generator
-and sliced (`sharded_randn`; an N-GPU run therefore reproduces the 1-GPU run sample for sample), and there is
-exactly ONE exchange: `gather_latents`, a single flat all_gather (RCCL over xGMI) of the finished latents.
-The VAE decode and the OpenCascade B-rep reconstruction that follow are outside this path.
+Multi-GPU: every op of the path is per-sample, so the batch is cut into contiguous per-rank slices (`shard_range`;
+sizes may differ by one, a rank may own nothing).  Noise:
+  * the four INITIAL latents keep the reference's seed semantics (utils.py:62-97): one seeded CPU generator draws the
+    whole batch, each rank keeps its slice (`sharded_randn`);
+  * the ANCESTRAL noise of the 2 x 250 DDPM steps is drawn on the device, as upstream does (sample.py:153), by a
+    counter-based generator keyed on (seed, draw number, GLOBAL sample index) (`device_randn` -> bg_philox_randn): a rank
+    draws only its own rows, nothing crosses PCIe, and an N-GPU run still reproduces the 1-GPU run sample for sample.
+    `noise_mode="reference"` restores the whole-batch CPU draw per step (parity mode against a CPU-driven cascade).
+There is exactly ONE exchange: `gather_latents`, a single flat all_gather (RCCL over xGMI) of the finished latents
+(and, when the caller decodes first, of the decoded point grids).  No step of the loops synchronises with the host.
 """
 import numpy as np
 import torch
@@ -22,7 +27,7 @@ from .utils import randn_tensor
 
 
 # --------------------------------------------------------------------------------------------------
-# sharding / the one collective
+# sharding / noise / the one collective
 # --------------------------------------------------------------------------------------------------
 def shard_range(n, rank, world):
     """Contiguous slice [lo, hi) of n samples owned by `rank` (sizes differ by at most 1)."""
@@ -38,110 +43,103 @@ def sharded_randn(shape, generator, rank, world, device):
     return full[lo:hi].to(device)
 
 
-def gather_latents(tensors, dist=None, group=None):
-    """All-gather a dict of per-rank tensors (batch on dim 0, equal per-rank batch) with ONE collective.
+def device_randn(shape, seed, draw_id, first_sample, device):
+    """N(0,1) of `shape` (= this rank's rows) drawn on the device; row b is global sample first_sample + b."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    if out.numel() == 0:
+        return out
+    if not out.is_cuda:
+        raise _lib.BrepgenHipError("device_randn runs on the MI355X only; there is no CPU fallback")
+    per = out[0].numel()
+    check(_lib.load().bg_philox_randn(ptr(out), shape[0], per, int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw_id) & 0xFFFFFFFF,
+                                      int(first_sample), 0, stream()), "bg_philox_randn")
+    return out
 
-    Everything is packed into one flat byte buffer (bool/uint8/fp32 alike) so the ring runs once with a large
-    message instead of once per tensor.  Returns the dict with the full batch on every rank."""
+
+def gather_latents(tensors, dist=None, group=None, batch_size=None):
+    """All-gather a dict of per-rank tensors (this rank's `shard_range` rows of a batch of `batch_size`, batch on
+    dim 0) with ONE collective; returns the dict with the full batch on every rank.
+
+    Everything is packed into one flat byte buffer (bool / uint8 / fp32 alike) so the ring runs once with a large
+    message instead of once per tensor.  Ranks may own different numbers of rows (or none): every rank pads its rows
+    to ceil(batch_size / world) before the collective -- all_gather needs equal contributions -- and the padding is
+    trimmed with `shard_range` afterwards.  batch_size=None means equal shards (world * local rows)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dict(tensors)
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     names = sorted(tensors)
+    local = tensors[names[0]].shape[0]
+    if batch_size is None:
+        batch_size = local * world
+    lo, hi = shard_range(batch_size, rank, world)
+    if hi - lo != local:
+        raise ValueError(f"rank {rank} holds {local} rows but owns {hi - lo} of a batch of {batch_size}")
+    rows = -(-batch_size // world)                                   # per-rank rows after padding
     flat, meta = [], []
     for k in names:
         t = tensors[k].contiguous()
-        b = t.view(torch.uint8) if t.dtype != torch.bool else t.view(torch.uint8)
+        if t.shape[0] != local:
+            raise ValueError(f"tensor {k!r} has {t.shape[0]} rows, expected {local}")
+        if local < rows:
+            t = torch.cat([t, t.new_zeros((rows - local,) + tuple(t.shape[1:]))])
+        b = t.view(torch.uint8)
         flat.append(b.reshape(-1))
-        meta.append((k, t.dtype, tuple(t.shape), b.numel()))
+        meta.append((k, t.dtype, tuple(t.shape[1:]), b.numel()))
     send = torch.cat(flat)
     pad = (-send.numel()) % 16
     if pad:
         send = torch.cat([send, send.new_zeros(pad)])
-    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    dev = send.device
+    if dist.get_backend(group) == "nccl":                            # RCCL: device buffers, one ring pass over xGMI
+        recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:                                                            # gloo (CPU tests): host staging
+        pieces = [torch.empty(send.numel(), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(pieces, send.cpu(), group=group)
+        recv = torch.cat(pieces).to(dev)
     recv = recv.view(world, -1)
+    counts = [b - a for a, b in (shard_range(batch_size, r, world) for r in range(world))]
     out, off = {}, 0
-    for k, dt, shape, nb in meta:
-        piece = recv[:, off:off + nb].contiguous().view(dt)
-        out[k] = piece.reshape((world * shape[0],) + shape[1:])
+    for k, dt, tail, nb in meta:
+        piece = recv[:, off:off + nb].contiguous().view(dt).reshape((world, rows) + tail)
+        out[k] = piece.reshape((world * rows,) + tail) if rows * world == batch_size else \
+            torch.cat([piece[r, :counts[r]] for r in range(world)])
         off += nb
     return out
 
 
 # --------------------------------------------------------------------------------------------------
-# de-duplication between the stages.  On the device (bg_dedup_*: no host sync inside the cascade) for CUDA tensors;
-# the numpy restatement of the reference's host loops is kept (`*_host`) as the checker of the device kernels.  Per sample -> shards with the batch.
+# de-duplication between the stages, on the device (bg_dedup_*: no host sync inside the cascade).  Per sample ->
+# shards with the batch.  (The numpy restatement of the reference's host loops that checks these kernels lives in
+# oracle/dedup.py.)
 # --------------------------------------------------------------------------------------------------
 def dedup_surfaces(surfPos, threshold):
     """sample.py:159-183.  surfPos [B,S,6] -> (surfPos padded with 0 [B,S,6], surfMask bool [B,S])."""
     if not surfPos.is_cuda:
-        raise _lib.BrepgenHipError("dedup_surfaces runs on the MI355X (use dedup_surfaces_host for host tensors)")
+        raise _lib.BrepgenHipError("dedup_surfaces runs on the MI355X only; there is no CPU fallback")
     B, S, _ = surfPos.shape
     x = surfPos.detach().to(torch.float32).contiguous()
     pos = torch.empty_like(x)
     mask = torch.empty(B, S, dtype=torch.uint8, device=x.device)
-    check(_lib.load().bg_dedup_surfaces(ptr(x), float(np.float32(threshold)), ptr(pos), ptr(mask), B, S, stream()),
-          "bg_dedup_surfaces")
+    if B > 0:
+        check(_lib.load().bg_dedup_surfaces(ptr(x), float(np.float32(threshold)), ptr(pos), ptr(mask), B, S, stream()),
+              "bg_dedup_surfaces")
     return pos, mask.view(torch.bool)
 
 
 def dedup_edges(edgePos, surfMask, threshold):
     """sample.py:242-261.  -> edgeM bool [B,S,E], True = padded face or duplicate edge."""
     if not edgePos.is_cuda:
-        raise _lib.BrepgenHipError("dedup_edges runs on the MI355X (use dedup_edges_host for host tensors)")
+        raise _lib.BrepgenHipError("dedup_edges runs on the MI355X only; there is no CPU fallback")
     B, S, E, _ = edgePos.shape
     x = edgePos.detach().to(torch.float32).contiguous()
     sm = surfMask.contiguous()
     sm = sm.view(torch.uint8) if sm.dtype == torch.bool else sm.to(torch.uint8)
     em = torch.empty(B, S, E, dtype=torch.uint8, device=x.device)
-    check(_lib.load().bg_dedup_edges(ptr(x), ptr(sm), float(np.float32(threshold)), ptr(em), B, S, E, stream()),
-          "bg_dedup_edges")
+    if B > 0:
+        check(_lib.load().bg_dedup_edges(ptr(x), ptr(sm), float(np.float32(threshold)), ptr(em), B, S, E, stream()),
+              "bg_dedup_edges")
     return em.view(torch.bool)
-
-
-def dedup_surfaces_host(surfPos, threshold):
-    """sample.py:159-183.  surfPos [B,S,6] (device) -> (surfPos padded with 0 [B,S,6], surfMask bool [B,S])."""
-    B, S, _ = surfPos.shape
-    host = np.round(surfPos.detach().float().cpu().numpy().reshape(B, S, 2, 3), 4)
-    pos = np.zeros((B, S, 6), dtype=np.float32)
-    mask = np.ones((B, S), dtype=bool)
-    for b in range(B):
-        keep = [host[b, 0]]
-        for bbox in host[b]:
-            cur = np.stack(keep)
-            same = np.abs(cur - bbox).max(-1).max(-1) < threshold
-            same_rev = np.abs(cur - bbox[::-1]).max(-1).max(-1) < threshold
-            if not (same.any() or same_rev.any()):
-                keep.append(bbox)
-        k = len(keep)
-        pos[b, :k] = np.stack(keep).reshape(k, 6)
-        mask[b, :k] = False
-    return torch.from_numpy(pos).to(surfPos.device), torch.from_numpy(mask).to(surfPos.device)
-
-
-def dedup_edges_host(edgePos, surfMask, threshold):
-    """sample.py:242-261.  -> edgeM bool [B,S,E], True = padded face or duplicate edge."""
-    B, S, E, _ = edgePos.shape
-    host = edgePos.detach().float().cpu().numpy().reshape(B, S, E, 2, 3)
-    smask = surfMask.cpu().numpy()
-    edgeM = np.repeat(smask[:, :, None], E, axis=2).copy()
-    for b in range(B):
-        valid_faces = np.nonzero(~smask[b])[0]
-        # the reference indexes edgeM with the position inside the list of valid faces (sample.py:246,257);
-        # valid faces are left-aligned after dedup_surfaces, so position == face index
-        for idx, s in enumerate(valid_faces):
-            keep = [host[b, s, 0]]
-            for e in range(E):
-                bbox = host[b, s, e]
-                cur = np.stack(keep)
-                same = np.abs(cur - bbox).max(-1).max(-1) < threshold
-                same_rev = np.abs(cur - bbox[::-1]).max(-1).max(-1) < threshold
-                if same.any() or same_rev.any():
-                    edgeM[b, idx, e] = True
-                else:
-                    keep.append(bbox)
-            edgeM[b, idx, 0] = False
-    return torch.from_numpy(edgeM).to(edgePos.device)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -160,21 +158,29 @@ def decode_latents(surf_vae, edge_vae, latents):
 
 
 class CascadeSampler:
-    """Runs stages 1-4 of sample.py on this rank's slice of the batch and all-gathers the latents."""
+    """Runs stages 1-4 of sample.py on this rank's slice of the batch and (by default) all-gathers the latents.
+
+    noise_mode: "device" (default) -- ancestral DDPM noise from the counter-based device generator, keyed on the global
+    sample index (reproducible for any number of ranks); "reference" -- whole-batch draw from the seeded CPU generator at
+    every step, sliced by rank (the reference's utils.randn_tensor semantics; what a CPU-driven oracle cascade can
+    reproduce bit for bit, at the price of B x S x E x 6 host randoms and a PCIe copy per step on every rank)."""
 
     def __init__(self, surfpos, surfz, edgepos, edgez, pndm, ddpm, *, use_cf=False, class_id=0, guidance=0.6,
-                 bbox_threshold=0.08, dist=None, autocast=True):
+                 bbox_threshold=0.08, dist=None, autocast=True, noise_mode="device"):
+        if noise_mode not in ("device", "reference"):
+            raise ValueError("noise_mode must be 'device' or 'reference'")
         self.nets = (surfpos, surfz, edgepos, edgez)
         self.pndm, self.ddpm = pndm, ddpm
         self.use_cf, self.class_id, self.w = use_cf, class_id, guidance
         self.thr = bbox_threshold
         self.dist = dist
         self.autocast = autocast
+        self.noise_mode = noise_mode
         self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
 
     # one guided / unguided eps evaluation + scheduler step
-    def _step(self, sched, net_call, x, t, t_dev, **kw):
+    def _step(self, sched, net_call, x, t, **kw):
         if self.use_cf:
             eps = net_call(True)
             return sched.step(eps, t, x, guidance=self.w, **kw).prev_sample
@@ -189,13 +195,45 @@ class CascadeSampler:
     def _rep(t, n):
         return t.repeat(n, *([1] * (t.dim() - 1))).contiguous()
 
+    def _empty(self, S2, E, dev, stop_after):
+        """What a rank that owns no sample contributes (it skips the compute but still joins the collective)."""
+        f = lambda *s: torch.empty((0,) + s, dtype=torch.float32, device=dev)
+        m = lambda *s: torch.empty((0,) + s, dtype=torch.bool, device=dev)
+        out = {"surfPos": f(S2, 6), "surfMask": m(S2)}
+        if stop_after == "surfPos":
+            return out
+        out["surfZ"] = f(S2, 48)
+        if stop_after == "surfZ":
+            return out
+        out.update(edgePos=f(S2, E, 6), edgeM=m(S2, E))
+        if stop_after == "edgePos":
+            return out
+        out["edgeZV"] = f(S2, E, 18)
+        return out
+
     @torch.no_grad()
     def sample(self, batch_size, num_surfaces, num_edges, generator=None, device="cuda",
-               pndm_pos_steps=158, ddpm_pos_steps=250, pndm_z_steps=None, stop_after=None):
+               pndm_pos_steps=158, ddpm_pos_steps=250, pndm_z_steps=None, stop_after=None, gather=True):
+        """-> dict of latents: the whole batch on every rank (gather=True), or this rank's rows only (gather=False;
+        pass them -- plus anything derived per sample, e.g. the VAE decode -- to `gather_latents(..., batch_size=)`)."""
         surfpos_net, surfz_net, edgepos_net, edgez_net = self.nets
         dev = torch.device(device)
         lo, hi = shard_range(batch_size, self.rank, self.world)
         b = hi - lo
+        finish = (lambda o: gather_latents(o, self.dist, batch_size=batch_size)) if gather else (lambda o: o)
+        # every rank consumes the CPU generator identically (4 whole-batch draws), whether or not it owns samples
+        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+        draw = [0]
+
+        def ancestral(shape, t):
+            """noise of one DDPM step for this rank's rows (None at t == 0, where upstream adds no variance)."""
+            draw[0] += 1
+            if int(t) == 0:
+                return None
+            if self.noise_mode == "reference":                      # every rank consumes the generator identically
+                return sharded_randn((batch_size,) + shape, generator, self.rank, self.world, dev)
+            return device_randn((b,) + shape, seed, draw[0], lo, dev)
+
         cl = self._labels(b, dev)
         # autocast=True -> bf16 operands; a torch dtype (torch.float16: the reference's own autocast dtype) selects it
         if self.autocast is True:
@@ -204,67 +242,83 @@ class CascadeSampler:
             ctx = torch.autocast("cuda", dtype=self.autocast)
         else:
             ctx = torch.autocast("cuda", enabled=False)
+        skip = b == 0
         with ctx:
             # ---- 1-1 surface positions ----
             S = num_surfaces
             x = sharded_randn((batch_size, S, 6), generator, self.rank, self.world, dev)
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps[:pndm_pos_steps]:
-                td = t.reshape(-1).to(dev)
-                x = self._step(self.pndm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t, td)
+            pndm_ts, pndm_dev = self.pndm.timesteps, self.pndm.timesteps.to(dev)     # ONE copy; steps take views
+            for i, t in enumerate(pndm_ts[:pndm_pos_steps]):
+                if skip:
+                    break
+                td = pndm_dev[i:i + 1]
+                x = self._step(self.pndm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t)
             if not self.use_cf:                                     # late doubling, sample.py:140-142
                 x = x.repeat(1, 2, 1).contiguous()
                 S *= 2
             self.ddpm.set_timesteps(1000)
-            for t in self.ddpm.timesteps[-ddpm_pos_steps:]:
-                td = t.reshape(-1).to(dev)
-                z = sharded_randn((batch_size, S, 6), generator, self.rank, self.world, dev) if int(t) > 0 else None
-                x = self._step(self.ddpm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t, td, noise=z)
+            ddpm_ts = self.ddpm.timesteps[-ddpm_pos_steps:]
+            ddpm_dev = ddpm_ts.to(dev)
+            for i, t in enumerate(ddpm_ts):
+                z = ancestral((S, 6), t)
+                if skip:
+                    continue
+                td = ddpm_dev[i:i + 1]
+                x = self._step(self.ddpm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t, noise=z)
             surfPos, surfMask = dedup_surfaces(x, self.thr)
             out = {"surfPos": surfPos, "surfMask": surfMask}
             if stop_after == "surfPos":
-                return gather_latents(out, self.dist)
+                return finish(out)
 
             # ---- 1-3 surface latents ----
             surfZ = sharded_randn((batch_size, S, 48), generator, self.rank, self.world, dev)
             sp2, sm2 = (self._rep(surfPos, 2), self._rep(surfMask, 2)) if self.use_cf else (surfPos, surfMask)
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps[:pndm_z_steps]:
-                td = t.reshape(-1).to(dev)
+            for i, t in enumerate(pndm_ts[:pndm_z_steps]):
+                if skip:
+                    break
+                td = pndm_dev[i:i + 1]
                 surfZ = self._step(self.pndm, lambda g: surfz_net(self._rep(surfZ, 2) if g else surfZ, td, sp2, sm2, cl),
-                                   surfZ, t, td)
+                                   surfZ, t)
             out["surfZ"] = surfZ
             if stop_after == "surfZ":
-                return gather_latents(out, self.dist)
+                return finish(out)
 
             # ---- 2-1 edge positions ----
             E = num_edges
             edgePos = sharded_randn((batch_size, S, E, 6), generator, self.rank, self.world, dev)
             sz2 = self._rep(surfZ, 2) if self.use_cf else surfZ
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps[:pndm_pos_steps]:
-                td = t.reshape(-1).to(dev)
+            for i, t in enumerate(pndm_ts[:pndm_pos_steps]):
+                if skip:
+                    break
+                td = pndm_dev[i:i + 1]
                 edgePos = self._step(self.pndm, lambda g: edgepos_net(self._rep(edgePos, 2) if g else edgePos, td, sp2,
-                                                                       sz2, sm2, cl), edgePos, t, td)
+                                                                       sz2, sm2, cl), edgePos, t)
             self.ddpm.set_timesteps(1000)
-            for t in self.ddpm.timesteps[-ddpm_pos_steps:]:
-                td = t.reshape(-1).to(dev)
-                z = sharded_randn((batch_size, S, E, 6), generator, self.rank, self.world, dev) if int(t) > 0 else None
+            for i, t in enumerate(ddpm_ts):
+                z = ancestral((S, E, 6), t)
+                if skip:
+                    continue
+                td = ddpm_dev[i:i + 1]
                 edgePos = self._step(self.ddpm, lambda g: edgepos_net(self._rep(edgePos, 2) if g else edgePos, td, sp2,
-                                                                       sz2, sm2, cl), edgePos, t, td, noise=z)
+                                                                       sz2, sm2, cl), edgePos, t, noise=z)
             edgeM = dedup_edges(edgePos, surfMask, self.thr)
             out.update(edgePos=edgePos, edgeM=edgeM)
             if stop_after == "edgePos":
-                return gather_latents(out, self.dist)
+                return finish(out)
 
             # ---- 2-3 edge latents + vertices ----
             edgeZV = sharded_randn((batch_size, S, E, 18), generator, self.rank, self.world, dev)
             ep2, em2 = (self._rep(edgePos, 2), self._rep(edgeM, 2)) if self.use_cf else (edgePos, edgeM)
             self.pndm.set_timesteps(200)
-            for t in self.pndm.timesteps[:pndm_z_steps]:
-                td = t.reshape(-1).to(dev)
+            for i, t in enumerate(pndm_ts[:pndm_z_steps]):
+                if skip:
+                    break
+                td = pndm_dev[i:i + 1]
                 edgeZV = self._step(self.pndm, lambda g: edgez_net(self._rep(edgeZV, 2) if g else edgeZV, td, ep2, sp2,
-                                                                    sz2, em2, cl), edgeZV, t, td)
+                                                                    sz2, em2, cl), edgeZV, t)
             edgeZV = edgeZV.masked_fill(edgeM.unsqueeze(-1), 0.0)   # sample.py:284
             out["edgeZV"] = edgeZV
-        return gather_latents(out, self.dist)
+        return finish(out)

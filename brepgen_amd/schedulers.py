@@ -125,9 +125,13 @@ class DDPMScheduler:
 
     def add_noise(self, original_samples, noise, timesteps):
         x0, z = _prep(original_samples), _prep(noise)
-        acp = self.alphas_cumprod[timesteps.reshape(-1).cpu().long()]
-        sa = (acp ** 0.5).to(x0.device).contiguous()
-        sb = ((1 - acp) ** 0.5).to(x0.device).contiguous()
+        # the table follows the samples onto the device once; the per-sample gather stays there (no host round trip
+        # when the trainer draws its timesteps on the device, trainer.py:346)
+        if getattr(self, "_acp_dev", None) is None or self._acp_dev.device != x0.device:
+            self._acp_dev = self.alphas_cumprod.to(x0.device)
+        acp = self._acp_dev.index_select(0, timesteps.reshape(-1).to(device=x0.device, dtype=torch.long))
+        sa = acp.sqrt().contiguous()                                 # correctly rounded, as the host pow(., 0.5) is
+        sb = (1 - acp).sqrt().contiguous()
         B = x0.shape[0]
         if sa.numel() != B:
             raise ValueError("add_noise needs one timestep per sample")

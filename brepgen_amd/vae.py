@@ -371,6 +371,8 @@ class AutoencoderKLFastDecode(_HipVAE):
         if not surfZ.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {surfZ.device})")
         lead = surfZ.shape[:-1]
+        if surfZ.numel() == 0:                                       # a rank that owns no sample of a sharded batch
+            return surfZ.new_zeros((*lead, *self._decode_cl_shape()), dtype=torch.float32)
         z_cl = surfZ.detach().to(torch.float32).reshape(-1, 4, 4, self.latent).contiguous()
         return self._decode_cl(z_cl).reshape(*lead, *self._decode_cl_shape())
 
@@ -450,6 +452,8 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         if not edgeZ.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {edgeZ.device})")
         lead = edgeZ.shape[:-1]
+        if edgeZ.numel() == 0:
+            return edgeZ.new_zeros((*lead, 4 * 2 ** len(self.block_out), self.out_ch), dtype=torch.float32)
         z_cl = edgeZ.detach().to(torch.float32).reshape(-1, 4, self.latent).contiguous()
         out = self._decode_cl(z_cl)
         return out.reshape(*lead, out.shape[1], out.shape[2])

@@ -286,6 +286,15 @@ int bg_add_noise(const float* x0, const float* noise, const float* sqrt_alpha_pr
                  const float* sqrt_one_minus_alpha_prod, float* out, int B, size_t per_sample,
                  bg_stream_t stream);
 
+/* Ancestral noise of the DDPM loops (the reference draws it on the device with the global RNG, sample.py:144-153 ->
+ * diffusers randn_tensor(device=...)): out[b, e] ~ N(0,1) for samples b = 0 .. n_samples-1 of `per_sample` elements,
+ * Philox4x32-10 with key = seed, counter = (e / 4, first_sample + b, draw_id, tag) and Box-Muller on the four words.
+ * The value of an element depends only on (seed, draw_id, GLOBAL sample index, e): a rank that owns samples
+ * [lo, hi) of a sharded batch passes first_sample = lo and reproduces exactly those rows of the single-GPU draw.
+ * raw_bits != 0 writes the four 32-bit words themselves (bit pattern in the float slots) -- used by the parity test. */
+int bg_philox_randn(float* out, long long n_samples, int per_sample, unsigned long long seed, unsigned draw_id,
+                    long long first_sample, int raw_bits, bg_stream_t stream);
+
 /* Device loop of joint_optimize (utils.py:746-772): per-face 3-D offsets fitted with `iters` AdamW steps (torch.optim.AdamW
  * arithmetic; the reference uses lr 1e-3, betas (0.95, 0.999), weight_decay 1e-6, eps 1e-8, 200 iterations) on
  *   L = mean_f sum_{e in edges_f} min_{s in surf_f} |e - (s + off_f)|^2        (chamferdist ChamferDistance(reverse=True)).

@@ -52,7 +52,7 @@ def linear(x, w, b):
 def sincos_embedding(t, dim=D_MODEL, max_period=10000):
     """network.py:1043-1063 -- note: cos block first, then sin block."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t.reshape(-1, 1).to(torch.float32) * freqs.reshape(1, -1)
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 

@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 
 def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, thr=0.08):
     """Reference order of operations, CPU: sample.py:126-286 with the oracle in place of network.py/diffusers."""
-    from brepgen_amd.sampling import dedup_edges_host as dedup_edges
-    from brepgen_amd.sampling import dedup_surfaces_host as dedup_surfaces
+    from oracle.dedup import dedup_edges_host as dedup_edges
+    from oracle.dedup import dedup_surfaces_host as dedup_surfaces
     from brepgen_amd.utils import randn_tensor
     from oracle import denoisers as orc
     from oracle.schedulers import OracleDDPM, OraclePNDM
@@ -77,7 +77,7 @@ def test_cascade_matches_oracle_cascade(use_cf):
     kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001,
               beta_end=0.02)
     sampler = CascadeSampler(*nets, bga.PNDMScheduler(**kw), bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw),
-                             use_cf=use_cf, class_id=6, guidance=0.6, autocast=False)
+                             use_cf=use_cf, class_id=6, guidance=0.6, autocast=False, noise_mode="reference")
     with torch.no_grad():
         got = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(11), pndm_pos_steps=n_pos,
                              ddpm_pos_steps=n_ddpm, pndm_z_steps=n_z)
@@ -95,7 +95,8 @@ def test_device_dedup_is_bit_identical_to_the_numpy_loops():
     """bg_dedup_surfaces / bg_dedup_edges vs the reference-order numpy code, incl. near-threshold and swapped boxes."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    from brepgen_amd.sampling import (dedup_edges, dedup_edges_host, dedup_surfaces, dedup_surfaces_host)
+    from brepgen_amd.sampling import dedup_edges, dedup_surfaces
+    from oracle.dedup import dedup_edges_host, dedup_surfaces_host
     g = torch.Generator().manual_seed(4)
     for B, S, E in [(5, 60, 30), (3, 100, 40), (2, 7, 3), (4, 64, 64)]:
         base = torch.randn(B, 6, 6, generator=g).clamp(-3, 3)                     # 6 prototypes per sample

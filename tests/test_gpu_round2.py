@@ -1,0 +1,182 @@
+"""-m gpu: round-2 additions -- counter-based device noise, sharded cascade over two real processes, attention rescale
+branch forced by construction, batch-size independence of the time-embedding dispatch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32, F16, BF16 = torch.float32, torch.float16, torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def pc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import parity_cases
+    return parity_cases
+
+
+# ---- bg_philox_randn vs oracle/philox.py -------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,per,first", [(5, 48, 0), (3, 6, 1000), (2, 7, 2 ** 33 + 5), (64, 360, 17), (1, 1, 0)])
+def test_philox_bits_exact_and_normals_close(pc, n, per, first):
+    from brepgen_amd import _lib
+    from oracle import philox as ph
+    lib = _lib.load()
+    seed, draw = 0xC0FFEE1234567, 9
+    raw = torch.empty(n, per, device="cuda", dtype=torch.float32)
+    _lib.check(lib.bg_philox_randn(raw.data_ptr(), n, per, seed, draw, first, 1, _lib.stream()), "philox raw")
+    z = torch.empty(n, per, device="cuda", dtype=torch.float32)
+    _lib.check(lib.bg_philox_randn(z.data_ptr(), n, per, seed, draw, first, 0, _lib.stream()), "philox")
+    got_bits = raw.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_bits, ph.raw_bits(n, per, seed, draw, first))          # integer work: bit exact
+    want = ph.randn(n, per, seed, draw, first)
+    assert np.abs(z.cpu().numpy() - want).max() < 2e-5                              # libm vs device log/sin/cos: ulps
+
+
+def test_device_randn_shards_reproduce_the_full_draw(pc):
+    from brepgen_amd.sampling import device_randn, shard_range
+    full = device_randn((10, 60, 6), 123, 4, 0, "cuda")
+    for world in (2, 3, 8):
+        parts = [device_randn((hi - lo, 60, 6), 123, 4, lo, "cuda") for lo, hi in (shard_range(10, r, world) for r in range(world))]
+        assert torch.equal(torch.cat(parts), full)
+    z = device_randn((4096, 60, 48), 5, 1, 0, "cuda")
+    assert abs(float(z.mean())) < 2e-3 and abs(float(z.std()) - 1) < 2e-3 and bool(torch.isfinite(z).all())
+
+
+# ---- the rescale branch of the online softmax, forced (guide rule 26) ---------------------------------------------------
+@pytest.mark.parametrize("N,spike_at", [(300, 70), (300, 299), (1800, 1000), (130, 64)])
+def test_attention_running_max_rescale_is_exact(pc, N, spike_at):
+    """One key far into the sequence gets a logit ~40 above everything before it for half of the queries: the running
+    max must jump at that tile and everything accumulated so far must be rescaled by exp(-40) -- a rescale slip of a
+    few percent shows up as an O(few %) relative error; asserted at the bf16 rounding of P and O (2^-8 relative)."""
+    from brepgen_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    qkv = torch.randn(B * N, 2304, generator=g)
+    qkv[:, :768] *= 0.25
+    q = qkv[:, :768].reshape(B, N, 12, 64)
+    k = qkv[:, 768:1536].reshape(B, N, 12, 64)
+    k[:, spike_at] = 0
+    k[:, spike_at, :, 0] = 40.0
+    q[:, ::2, :, 0] = 1.0                                 # even queries: logit 40 on the spike key
+    q[:, 1::2, :, 0] = -1.0                               # odd queries: logit -40 (the spike must vanish for them)
+    qd = qkv.to(BF16)
+    want = pc._attn_ref(qd, None, B, N)
+    got = ops.attention(qd.cuda(), None, B, N).float().cpu().double()
+    rel = float((got - want).abs().max() / want.abs().max())
+    assert torch.isfinite(got).all() and rel < 1.0 / 128, rel
+
+
+def test_attention_bf16_relative_error_with_wide_logits(pc):
+    e = pc.attn_case(2, 300, BF16, None, seed=5, scale=3.0)
+    assert e["finite"] and e["max_abs"] < e["ref_absmax"] / 100 and e["mean_abs"] < 8e-3
+
+
+# ---- dispatch rule of the time-embedding GEMV ---------------------------------------------------------------------------
+def test_per_sample_timesteps_are_batch_size_independent(pc):
+    """fp32 mode, one timestep PER SAMPLE (the trainers' call, trainer.py:346): M = B rows enter the time MLP, which must
+    take the MFMA kernel for every B (the GEMV is reserved for the single shared timestep), so a sample's eps has the
+    same bits in a batch of 3 and in a batch of 12."""
+    m, _ = pc.build_net("SurfZNet", 5, False, F32)
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfZNet", 12, 20, 1, False)]
+    t = torch.tensor([7, 500, 999, 3, 250, 0, 1, 998, 42, 77, 640, 123], device="cuda")
+    with torch.no_grad():
+        big = m(args[0], t, args[2], args[3], None)
+        small = m(args[0][:3].contiguous(), t[:3], args[2][:3].contiguous(), args[3][:3].contiguous(), None)
+    assert torch.equal(big[:3], small)
+    with torch.no_grad():                                 # and the shared-timestep path is batch independent as well
+        t1 = torch.tensor([249], device="cuda")
+        big = m(args[0], t1, args[2], args[3], None)
+        one = m(args[0][5:6].contiguous(), t1, args[2][5:6].contiguous(), args[3][5:6].contiguous(), None)
+    assert torch.equal(big[5:6], one)
+
+
+def test_hip_graph_with_conditioning_updates(pc):
+    """A captured eps-eval must pick up NEW conditioning written into the static buffers (the conditioning cache is
+    bypassed during capture, so nothing step-invariant is baked into the graph)."""
+    m, _ = pc.build_net("SurfZNet", 6, False, BF16)
+    a = [x.cuda() if torch.is_tensor(x) else x for x in pc.synth_inputs("SurfZNet", 4, 30, 1, False)]
+    z, t, pos, mask = a[0].clone(), a[1].cuda(), a[2].clone(), a[3]
+    with torch.no_grad():
+        m(z, t, pos, mask, None)                          # warm-up outside capture (packs weights, sizes the workspace)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(z, t, pos, mask, None)
+        pos2 = (pos * 0.5 + 0.3).contiguous()
+        pos.copy_(pos2)                                   # new conditioning, same buffer
+        g.replay()
+        torch.cuda.synchronize()
+        m.cache_conditioning = False
+        want = m(z, t, pos2, mask, None)
+    assert torch.equal(out, want)
+
+
+# ---- the sharded cascade over two real processes ------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build_sampler(dist, use_cf, noise_mode):
+    import brepgen_amd as bga
+    from brepgen_amd.sampling import CascadeSampler
+    from oracle import denoisers as orc
+    nets = []
+    for i, n in enumerate(["SurfPosNet", "SurfZNet", "EdgePosNet", "EdgeZNet"]):
+        m = getattr(bga, n)(use_cf)
+        m.load_state_dict(orc.seeded_state_dict(n, 50 + i, use_cf), strict=True)
+        nets.append(m.cuda().eval())
+    kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001, beta_end=0.02)
+    return CascadeSampler(*nets, bga.PNDMScheduler(**kw), bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw),
+                          use_cf=use_cf, class_id=6, guidance=0.6, autocast=True, dist=dist, noise_mode=noise_mode)
+
+
+SCHED = dict(pndm_pos_steps=13, ddpm_pos_steps=4, pndm_z_steps=13)
+
+
+def _rank_main(rank, world, port, B, S, E, noise_mode, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)                              # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sampler = _build_sampler(dist, False, noise_mode)
+        out = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(31), **SCHED)
+        q.put((rank, {k: v.cpu() for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,noise_mode", [(2, "device"), (2, "reference"), (4, "device")])
+def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
+    """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with an UNEVEN split --
+    B = 3 samples: world 2 -> shards of 2 and 1, world 4 -> one rank owns nothing -- equals the single-process cascade
+    bit for bit: per-sample kernels, noise keyed on the global sample index, one padded all-gather."""
+    import torch.multiprocessing as mp
+    B, S, E = 3, 4, 3
+    want = _build_sampler(None, False, noise_mode).sample(B, S, E, generator=torch.Generator().manual_seed(31), **SCHED)
+    want = {k: v.cpu() for k, v in want.items()}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, B, S, E, noise_mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert set(got[r]) == set(want)
+        for k in want:
+            assert got[r][k].shape == want[k].shape and got[r][k].dtype == want[k].dtype, (r, k)
+            assert torch.equal(got[r][k], want[k]), f"rank {r} tensor {k}"

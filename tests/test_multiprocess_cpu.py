@@ -8,8 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from brepgen_amd.sampling import dedup_edges_host as dedup_edges
-from brepgen_amd.sampling import dedup_surfaces_host as dedup_surfaces
+from oracle.dedup import dedup_edges_host as dedup_edges
+from oracle.dedup import dedup_surfaces_host as dedup_surfaces
 from brepgen_amd.sampling import gather_latents, shard_range, sharded_randn
 
 

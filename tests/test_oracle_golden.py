@@ -55,3 +55,18 @@ def test_masked_keys_do_not_influence_valid_tokens():
 def test_sincos_cos_first():
     e = orc.sincos_embedding(torch.tensor([0]))
     assert torch.all(e[0, :384] == 1) and torch.all(e[0, 384:] == 0)
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST["cases"]))
+def test_reference_formulation_matches_reference_golden(name):
+    """oracle/ref_formulation.py (stock nn.TransformerEncoder, seq-first -- the like-for-like autocast target and the
+    CPU-baseline formulation) loads the reference-keyed weights strictly and reproduces the reference's own outputs."""
+    from oracle import ref_formulation as rf
+    meta, args, want = load_case(name)
+    sd = orc.seeded_state_dict(meta["net"], meta["weight_seed"], meta["use_cf"])
+    m = rf.build(meta["net"], sd, meta["use_cf"])
+    with torch.no_grad():
+        got = m(*args)
+    assert got.shape == want.shape
+    valid = torch.isfinite(want)
+    assert float((got - want)[valid].abs().max()) < 1e-5
