@@ -43,6 +43,7 @@ def make_inputs(B, device, seed):
     nvalid = torch.randint(8, N_FACE + 1, (B,), generator=g)          # valid faces per sample ~ U{8..60}
     for b in range(B):
         mask[b, : int(nvalid[b])] = False
+    make_inputs.nvalid = nvalid                                       # host-side copy: FLOP accounting only
     return z.to(device), pos.to(device), mask.to(device)
 
 
@@ -146,7 +147,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the measurements reported beside the headline")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + JSON only, on CPU (no compute)")
+    ap.add_argument("--dense", action="store_true", help="run every padded position like the reference (no compaction)")
     args = ap.parse_args()
 
     ap_world = os.environ.get("WORLD_SIZE")
@@ -203,7 +206,11 @@ def main():
     net = bga.SurfZNet(False).to(dev).eval()
     net.compute_dtype = torch.bfloat16
     net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
+    net.varlen = not args.dense        # variable-length execution: only the valid faces (U{8..60} of 60) run through the net
     z, pos, mask = make_inputs(B_PER_GPU, dev, 1234 + rank)
+    nvalid = make_inputs.nvalid.double()
+    if net.varlen:                     # the opt-in profiler books EXECUTED rows / attention pairs (host-side knowledge)
+        net.profile_hints = (float(nvalid.sum()), float((nvalid * nvalid).sum()))
     sch = bga.DDPMScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
                             beta_start=0.0001, beta_end=0.02, clip_sample=True, clip_sample_range=3)
     sch.set_timesteps(1000)
@@ -239,6 +246,22 @@ def main():
         elapsed = float(tt)
     finite = bool(torch.isfinite(out["surfZ"]).all())
 
+    extra = {}
+    if net.varlen and not args.no_extra:
+        # the same K steps with dense execution (every padded position computed, as the reference does) -- reported
+        # beside the headline, never part of `value`
+        net.varlen, hints = False, net.profile_hints
+        net.profile_hints = None
+        run_steps(2, x, 0)
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps, x, args.warmup)
+        barrier()
+        d_el = time.perf_counter() - t1
+        extra["dense_execution"] = {"ms_per_step": round(1e3 * d_el / args.steps, 4),
+                                    "steps_per_s_per_gpu": round(args.steps / d_el, 3)}
+        net.varlen, net.profile_hints = True, hints
+
     roofline = None
     breakdown = None
     if not args.no_roofline:
@@ -261,6 +284,10 @@ def main():
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
         f_step = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 3.70e6)
+        # executed: F(n_b) summed over the samples (n_b valid faces each); the padded conditioning embed p_embed(surfPos)
+        # (2.44 MFLOP per face) still runs on all 60 faces
+        f_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), 3.70e6 - 2.44e6) for n in nvalid)) + \
+            B_PER_GPU * N_FACE * 2.44e6 if net.varlen else f_step
         line = {
             "metric": "denoising-steps/sec (whole node), DeepCAD face-LDM, batch=512",
             "value": round(steps_per_s, 3), "unit": "denoising-steps/s (batch=512 per step)",
@@ -272,11 +299,16 @@ def main():
                        "batch_per_gpu": B_PER_GPU, "tokens_per_sample": N_FACE,
                        "sample_steps_per_s": round(steps_per_s * B_PER_GPU, 1),
                        "algorithmic_tflop_per_step": round(f_step / 1e12, 3),
+                       "executed_tflop_per_step": round(f_exec / 1e12, 3),
+                       "varlen": bool(net.varlen), "valid_faces_per_sample_mean": round(float(nvalid.mean()), 2),
                        "model_tflops_per_gpu": round(f_step * args.steps / elapsed / 1e12, 1),
+                       "executed_tflops_per_gpu": round(f_exec * args.steps / elapsed / 1e12, 1),
                        "finite": finite, "parallelism": f"batch-sharded x{world}, 1 all_gather of latents",
-                       "formulation": "norm1/norm2 folded into the QKV/FFN1 GEMM epilogues, residual stream as (hi, lo) "
-                                      "16-bit planes, fused input embeds; conditioning cache off (every embed recomputed)"},
-            "roofline": roofline, "kernels": breakdown,
+                       "formulation": "variable-length execution (valid faces compacted on the device; eps = 0 at padded "
+                                      "positions, valid positions as the dense path), norm1/norm2 folded into the QKV/FFN1 "
+                                      "GEMM epilogues, residual stream as (hi, lo) 16-bit planes, fused input embeds; "
+                                      "conditioning cache off (every embed recomputed)"},
+            "roofline": roofline, "kernels": breakdown, "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

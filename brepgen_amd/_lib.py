@@ -43,7 +43,8 @@ class DenoiserInputs(C.Structure):
     _fields_ = [("B", C.c_int), ("S", C.c_int), ("E", C.c_int), ("n_timesteps", C.c_int),
                 ("x", fp), ("surf_pos", fp), ("surf_z", fp), ("edge_pos", fp), ("mask", u8p),
                 ("timesteps", i64p), ("class_label", i64p), ("cond_cache", fp),
-                ("cond_cache_valid", C.c_int), ("_pad", C.c_int)]
+                ("cond_cache_valid", C.c_int), ("varlen", C.c_int), ("rows_hint", C.c_double),
+                ("pairs_hint", C.c_double)]
 
 
 class GemmDesc(C.Structure):          # bg_gemm_desc
@@ -119,7 +120,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export the ABI
             fn.restype, fn.argtypes = res, args
-        if lib.bg_abi_version() != 2:
+        if lib.bg_abi_version() != 3:
             raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
         for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):     # A/B knobs, e.g. BG_TUNE="0=10,5=1"
             k, v = kv.split("=")

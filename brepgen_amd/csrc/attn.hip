@@ -38,7 +38,8 @@ template <> struct AElem<true> {
 
 template <int WPH, bool F16>
 __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
-                                                        void* __restrict__ out_, int B, int N) {
+                                                        void* __restrict__ out_, int B, int N,
+                                                        const int* __restrict__ offsets) {
     using E = AElem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -58,7 +59,15 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
     const int q0 = (blockIdx.x * WPH + qt) * 32;
     unsigned char* ktile = lds + hl * HEAD_LDS;
     T* vt = reinterpret_cast<T*>(ktile + 64 * 128);
-    const T* base = qkv + (size_t)b * N * QKV_LD + head * 64;
+    // compacted batch: sample b owns rows offsets[b] .. offsets[b+1]-1, every one a valid key (no mask)
+    size_t row_base = (size_t)b * N;
+    if (offsets) {
+        row_base = (size_t)offsets[b];
+        N = offsets[b + 1] - offsets[b];
+        key_pad = nullptr;
+        if ((int)(blockIdx.x * WPH * 32) >= N) return;            // uniform per workgroup (also N == 0), before any barrier
+    }
+    const T* base = qkv + row_base * QKV_LD + head * 64;
 
     // Q fragments (B operand of S^T = K Q^T): lane = (query l&31, k-chunk h) for each 16-wide slice of d
     V8 qf[4];
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
         }
         if (tid < 64) {
             const int key = kt * 64 + tid;
-            const bool dead = key >= N || (key_pad != nullptr && key_pad[(size_t)b * N + key] != 0);
+            const bool dead = key >= N || (key_pad != nullptr && key_pad[row_base + key] != 0);
             mb[tid] = dead ? -INFINITY : 0.f;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int q = q0 + (lane & 31);
     if (q < N) {
-        T* op = out + ((size_t)b * N + q) * BG_D_MODEL + head * 64;
+        T* op = out + (row_base + q) * BG_D_MODEL + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -199,14 +208,21 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__ qkv,
                                                        const uint8_t* __restrict__ key_pad,
-                                                       float* __restrict__ out, int B, int N) {
+                                                       float* __restrict__ out, int B, int N,
+                                                       const int* __restrict__ offsets) {
     extern __shared__ float dyn[];                     // 4 waves x N probabilities
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
     const int head = blockIdx.y, b = blockIdx.z;
     float* p = dyn + (size_t)wave * N;
+    size_t row_base = (size_t)b * N;
+    if (offsets) {                                     // compacted batch (see attn16_kernel)
+        row_base = (size_t)offsets[b];
+        N = offsets[b + 1] - offsets[b];
+        key_pad = nullptr;
+    }
     if (q >= N) return;                                // no block-level barriers below
-    const float* base = qkv + (size_t)b * N * QKV_LD + head * 64;
+    const float* base = qkv + row_base * QKV_LD + head * 64;
     const float* qp = base + (size_t)q * QKV_LD;
     float qv[64];
 #pragma unroll
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     float mloc = -INFINITY;
     for (int j = lane; j < N; j += 64) {
         float sc;
-        if (key_pad != nullptr && key_pad[(size_t)b * N + j] != 0) {
+        if (key_pad != nullptr && key_pad[row_base + j] != 0) {
             sc = -INFINITY;
         } else {
             const float* kp = base + (size_t)j * QKV_LD + BG_D_MODEL;
@@ -239,29 +255,32 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float acc = 0.f;                                   // lane = d
     for (int j = 0; j < N; ++j) acc = fmaf(p[j], base[(size_t)j * QKV_LD + 2 * BG_D_MODEL + lane], acc);
-    out[((size_t)b * N + q) * BG_D_MODEL + head * 64 + lane] = l > 0.f ? acc / l : 0.f;
+    out[(row_base + q) * BG_D_MODEL + head * 64 + lane] = l > 0.f ? acc / l : 0.f;
 }
 
-int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s) {
+int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
+              const int* offsets, double pairs_hint) {
     if (B <= 0 || N <= 0) return 0;
     const double es = dtype == BG_F32 ? 4.0 : 2.0;
     // algorithmic: QK^T + PV over all heads, no mask discount; bytes: qkv read once, out written once
-    ProfScope prof(dtype == BG_F32 ? PK_ATTN_F32 : PK_ATTN_BF16, 4.0 * B * BG_N_HEAD * (double)N * N * BG_D_HEAD,
-                   es * B * (double)N * (QKV_LD + BG_D_MODEL), s);
+    // (compacted batch: pairs_hint = expected sum over samples of n_b^2, for the opt-in profiler only)
+    const double pairs = (offsets && pairs_hint > 0) ? pairs_hint : (double)B * N * N;
+    ProfScope prof(dtype == BG_F32 ? PK_ATTN_F32 : PK_ATTN_BF16, 4.0 * BG_N_HEAD * pairs * BG_D_HEAD,
+                   es * (pairs / N) * (QKV_LD + BG_D_MODEL), s);
     if (dtype == BG_BF16 || dtype == BG_F16) {
         const bool f16 = dtype == BG_F16;
         if (N <= 32) {
             const dim3 grid(1, BG_N_HEAD / 4, B);
-            if (f16) hipLaunchKernelGGL((attn16_kernel<1, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
-            else hipLaunchKernelGGL((attn16_kernel<1, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<1, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
+            else hipLaunchKernelGGL((attn16_kernel<1, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
         } else if (N <= 64) {
             const dim3 grid(1, BG_N_HEAD / 2, B);
-            if (f16) hipLaunchKernelGGL((attn16_kernel<2, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
-            else hipLaunchKernelGGL((attn16_kernel<2, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<2, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
+            else hipLaunchKernelGGL((attn16_kernel<2, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
         } else {
             const dim3 grid((N + 127) / 128, BG_N_HEAD, B);
-            if (f16) hipLaunchKernelGGL((attn16_kernel<4, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
-            else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N);
+            if (f16) hipLaunchKernelGGL((attn16_kernel<4, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
+            else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
         }
         return launch_status("attn16");
     }
@@ -275,7 +294,7 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         hipLaunchKernelGGL(attn_f32_kernel, dim3((N + 3) / 4, BG_N_HEAD, B), dim3(256), shm, s,
-                           reinterpret_cast<const float*>(qkv), key_pad, reinterpret_cast<float*>(out), B, N);
+                           reinterpret_cast<const float*>(qkv), key_pad, reinterpret_cast<float*>(out), B, N, offsets);
         return launch_status("attn_f32");
     }
     set_error("attention: unsupported dtype %d", dtype);
@@ -288,5 +307,5 @@ extern "C" int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, i
                            bg_stream_t stream) {
     BG_REQUIRE(qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_attn_fwd: null pointer or negative size");
     BG_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, BG_E_ALIGN, "bg_attn_fwd: 16-byte alignment");
-    return bg::attention(qkv, key_pad, out, B, N, dtype, (hipStream_t)stream);
+    return bg::attention(qkv, key_pad, out, B, N, dtype, (hipStream_t)stream, nullptr, 0.0);
 }

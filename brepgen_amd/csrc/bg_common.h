@@ -109,6 +109,14 @@ struct GemmArgs {
     // chain -- last-bit different, so only callers whose M never depends on the batch composition set it: the
     // time-embedding MLP)
     int gemv_ok = 0;
+    // ---- variable-length (compacted) batches: the number of rows actually present is only known on the device ----
+    // m_dev != null: *m_dev (<= M) rows exist; M stays the host-side upper bound that sizes the grid and the part-major
+    // statistics stride.  row_map[r] = index of compact row r in the PADDED token layout: addend rows (map_add / map_add2:
+    // add[(row_map[r] / add_div)]) and output rows (map_out: out[row_map[r]]) are looked up through it.
+    const int* m_dev = nullptr;
+    const int* row_map = nullptr;
+    int map_add = 0, map_add2 = 0, map_out = 0;
+    double rows_hint = 0.0;           // expected *m_dev, used only by the opt-in profiler's FLOP / byte accounting
 };
 
 // 4 x 16-bit (bf16 | fp16) payload <-> floats
@@ -171,15 +179,24 @@ int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s);   // ab_dtype: B
 int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s);
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps,
-                 int silu, hipStream_t s);
+                 int silu, hipStream_t s, const int* m_dev = nullptr);
 // same, input rows given as the split pair x = hi + lo (16-bit planes of dtype y_dtype)
 int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
-                       float eps, hipStream_t s);
+                       float eps, hipStream_t s, const int* m_dev = nullptr);
 // h = SiLU(LayerNorm(x W0^T + b0)) for k in {6, 12, 48}; w0p = W0 in MFMA operand order (embed.hip)
 bool embed_ln_silu_supported(int k);
+// (m_dev / src_row: compacted batches -- *m_dev rows exist, row r reads x[src_row[r]])
 int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
-                  const float* b, void* out, int out_dtype, float eps, hipStream_t s);
-int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s);
+                  const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev = nullptr,
+                  const int* src_row = nullptr);
+// offsets != null: compacted batch -- sample b owns qkv / out rows offsets[b] .. offsets[b+1]-1 (<= N of them, all valid
+// keys; key_pad is ignored); otherwise sample b owns rows b*N .. b*N+N-1 and key_pad marks the padded keys.
+int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
+              const int* offsets = nullptr, double pairs_hint = 0.0);
+// valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
+// covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),
+// src_row [B * n_mask * rep]: padded-layout index of every compact row, in order.
+int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s);
 int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
 // c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)
 int cond_vector(const float* temb, int nt, const float* class_embed, const int64_t* label, float* c, int B,

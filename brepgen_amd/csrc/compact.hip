@@ -1,0 +1,92 @@
+// Valid-token compaction of a padded batch (variable-length execution of the denoisers).
+//
+// The reference pads every sample to max_face (x max_edge) tokens and masks the padding as attention KEYS only
+// (network.py:1196, 1283, 1390 -> src_key_padding_mask); the padded tokens still run through all 12 layers and their
+// outputs are thrown away (sample.py:284, 307-314 read valid rows only).  No op of the path mixes tokens except
+// attention, and a padded key never reaches a valid query -- so the valid tokens of each sample can be packed into
+// consecutive rows, every GEMM / LayerNorm runs on sum(valid) rows, attention runs per sample over its own rows, and
+// the result is scattered back into the padded layout (padded positions: 0).
+//
+// mask [B, n_mask] uint8, 1 = padded; each entry covers `rep` consecutive tokens (EdgePosNet: one entry per face,
+// rep = E).  Three tiny launches, all integer work, no host round trip: the row count stays on the device (offsets[B])
+// and every consumer kernel reads it from there.
+#include "bg_common.h"
+
+namespace bg {
+
+__global__ __launch_bounds__(256) void count_valid_kernel(const uint8_t* __restrict__ mask, int n_mask, int rep,
+                                                          int* __restrict__ counts) {
+    __shared__ int part[4];
+    const uint8_t* m = mask + (size_t)blockIdx.x * n_mask;
+    int c = 0;
+    for (int i = threadIdx.x; i < n_mask; i += 256) c += m[i] == 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (part[0] + part[1] + part[2] + part[3]) * rep;
+}
+
+// exclusive scan of counts[0..B) -> offsets[0..B]; one block, B <= a few thousand
+__global__ __launch_bounds__(1024) void scan_offsets_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < B ? counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan
+            const int t = threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < B) offsets[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[B] = carry;
+}
+
+// src_row[offsets[b] + j] = padded-layout index of the j-th valid token of sample b (order preserved)
+__global__ __launch_bounds__(256) void fill_rows_kernel(const uint8_t* __restrict__ mask, int n_mask, int rep,
+                                                        const int* __restrict__ offsets, int* __restrict__ src_row) {
+    __shared__ int wsum[4];
+    __shared__ int running;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t* m = mask + (size_t)b * n_mask;
+    if (threadIdx.x == 0) running = offsets[b];
+    __syncthreads();
+    for (int base = 0; base < n_mask; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool valid = i < n_mask && m[i] == 0;
+        const unsigned long long bal = __ballot(valid);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        if (valid) {
+            const int dst = running + (wbase + before) * rep;
+            for (int e = 0; e < rep; ++e) src_row[dst + e] = (b * n_mask + i) * rep + e;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running += (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * rep;
+        __syncthreads();
+    }
+}
+
+int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s) {
+    ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * (2.0 + 4.0 * rep), s);
+    // counts live in src_row's tail?  no: keep it simple -- offsets[1..B] doubles as the count buffer before the scan
+    hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, rep, offsets + 1);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, s, offsets + 1, B, offsets);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, rep, offsets, src_row);
+    return launch_status("compact_rows");
+}
+
+}  // namespace bg

@@ -60,7 +60,7 @@ __global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __re
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, total;
+    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, off_rows, total;
     int M, F;
 };
 
@@ -77,6 +77,7 @@ static Workspace plan(int net, int B, int S, int E, int dtype) {
     w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
     w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
     w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.M * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
+    w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2) * 4) + align_up((size_t)w.M * 4) : 0;   // var-len: offsets, row map
     w.total = o;
     return w;
 }
@@ -97,32 +98,51 @@ struct Ctx {
     void* XH = nullptr;
     void* XL = nullptr;
     float* stats = nullptr;
+    // variable-length execution: valid tokens compacted into rows 0 .. *m_dev-1 (csrc/compact.hip)
+    const int* m_dev = nullptr;       // device-side row count (offsets[B])
+    const int* src_row = nullptr;     // compact row -> padded-layout token index
+    const int* offsets = nullptr;     // per-sample first row, [B+1]
+    int N_tok = 1;                    // tokens per sample of the padded layout
+    double rows_hint = 0.0, pairs_hint = 0.0;
 };
 
 // Linear(k,768)+b -> LN -> SiLU -> Linear(768,n)+b (+adds) ; x fp32 rows (lda), or activations in compute dtype for fc_out
 // `to_stream`: the result goes to the token stream X -- fp32 rows (out = c.X, and add == c.X accumulates), or, in
 // fold mode, the split pair (XH, XL) with row statistics (accumulating = the stream is the addend)
+// `tok`: the rows are tokens.  In a variable-length run they are the COMPACT rows (count on the device): the inputs are
+// gathered through c.src_row, the broadcast addends are looked up through it (map_add: `add` is indexed by the padded
+// token index / add_div; map_add2 likewise), and with `scatter` the result rows go back to the padded layout.
 static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, int rows, float* out, int ldc,
                      const float* add, int ld_add, int add_div, const float* add2, int ld_add2, int add2_div,
-                     bool to_stream = false) {
+                     bool to_stream = false, bool tok = false, bool gather = false, bool map_add = false,
+                     bool map_add2 = false, bool scatter = false) {
     int rc;
+    const bool vl = tok && c.m_dev != nullptr;
+    const int* m_dev = vl ? c.m_dev : nullptr;
+    const double hint = vl ? c.rows_hint : 0.0;
     if (m.w0_mfma && m.w0_dtype == BG_F32 && embed_ln_silu_supported(m.k_in)) {
         // input embeds (k = 6 / 12 / 48): Linear + LayerNorm + SiLU in one kernel, nothing but the result written
         rc = embed_ln_silu(reinterpret_cast<const float*>(x), lda, rows, m.k_in, m.w0_mfma, m.b0, m.ln_g, m.ln_b, c.H,
-                           c.dtype, 1e-5f, c.s);
+                           c.dtype, 1e-5f, c.s, m_dev, (vl && gather) ? c.src_row : nullptr);
         if (rc) return rc;
     } else {
+        BG_REQUIRE(!(vl && gather), BG_E_ARG, "bg_denoiser_fwd: variable-length execution needs the fused input embeds (w0_mfma)");
         float* t0 = reinterpret_cast<float*>(c.R);
         GemmArgs g1{x, lda, m.w0, m.b0, t0, 768, rows, 768, 768, m.k_in, BG_F32, BG_ACT_NONE, nullptr, 0, 1};
         g1.gemv_ok = (&m == &c.w->time_embed);                    // one row per distinct timestep
+        g1.m_dev = m_dev; g1.rows_hint = hint;
         rc = gemm(g1, m.w0_dtype, c.s);
         if (rc) return rc;
-        rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s);
+        rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s, m_dev);
         if (rc) return rc;
     }
     GemmArgs g2{c.H, 768, m.w3, m.b3, out, ldc, rows, m.n_out, m.n_out_pad, 768, BG_F32, BG_ACT_NONE, add, ld_add,
                 add ? add_div : 1};
     g2.add2 = add2; g2.ld_add2 = ld_add2; g2.add2_div = add2 ? add2_div : 1;
+    g2.m_dev = m_dev; g2.rows_hint = hint;
+    if (vl && (map_add || map_add2 || scatter)) {
+        g2.row_map = c.src_row; g2.map_add = map_add; g2.map_add2 = map_add2; g2.map_out = scatter;
+    }
     if (to_stream && c.fold) {
         g2.out = c.XH; g2.out_dtype = c.dtype; g2.out_lo = c.XL; g2.stats_out = c.stats;
         if (add == c.X) {                                         // accumulate into the stream
@@ -166,6 +186,22 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         c.XL = reinterpret_cast<unsigned char*>(c.X) + (size_t)M * 768 * 2;
         c.stats = reinterpret_cast<float*>(c.ws + c.p.off_stats);
     }
+    // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
+    const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
+    c.N_tok = N;
+    if (varlen) {
+        int* offs = reinterpret_cast<int*>(c.ws + c.p.off_rows);
+        int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2) * 4));
+        const int n_mask = (net == BG_EDGEPOS) ? S : N, rep = (net == BG_EDGEPOS) ? E : 1;
+        int rcc = compact_rows(in->mask, B, n_mask, rep, offs, srow, s);
+        if (rcc) return rcc;
+        c.offsets = offs; c.m_dev = offs + B; c.src_row = srow;
+        c.rows_hint = in->rows_hint > 0 ? in->rows_hint : 0.0;
+        c.pairs_hint = in->pairs_hint > 0 ? in->pairs_hint : 0.0;
+        // padded positions of the result are defined as 0 (the valid rows are scattered over this)
+        const hipError_t he = hipMemsetAsync(eps_out, 0, (size_t)M * w->fc_out.n_out * sizeof(float), s);
+        BG_REQUIRE(he == hipSuccess, (int)he, "bg_denoiser_fwd: hipMemsetAsync failed: %s", hipGetErrorString(he));
+    }
     float* small = reinterpret_cast<float*>(c.ws + c.p.off_small);
     float* sc = small;                         // [nt,768] sincos
     float* temb = small + (size_t)3 * B * 768; // [nt,768]
@@ -195,23 +231,27 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         case BG_SURFPOS:   // tokens = p_embed(x) + c
             rc = embed_mlp(c, w->embed[0], in->x, 6, M, c.X, 768, cvec, 768, N, nullptr, 0, 1, true);
             break;
+        // (variable-length: rows are the compact tokens; x is gathered, cvec [B] and the per-face conditioning
+        //  fcond [B*S] -- kept in the padded layout, so the conditioning cache is unaffected -- are looked up through the
+        //  row map: sample = token / N, face = token / E)
         case BG_SURFZ:     // tokens = z_embed(x) + p_embed(surfPos) + c
-            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1, true);
+            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1, true, true, true, true, true);
             break;
         case BG_EDGEPOS:   // tokens = edgep_embed(x) + surf[m/E] + c
-            rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E, true);
+            rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E, true, true, true, true, true);
             break;
         default:           // EdgeZ: edgez_embed(x[:, :12]) + vertp_fc(x[:, 12:]) + edgep_embed(edgePos) + surf[m/E] + c
-            rc = embed_mlp(c, w->embed[3], in->x, 18, M, c.X, 768, cvec, 768, N, fcond, 768, E, true);
-            if (!rc) rc = embed_mlp(c, w->embed[4], in->x + 12, 18, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true);
-            if (!rc) rc = embed_mlp(c, w->embed[2], in->edge_pos, 6, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true);
+            rc = embed_mlp(c, w->embed[3], in->x, 18, M, c.X, 768, cvec, 768, N, fcond, 768, E, true, true, true, true, true);
+            if (!rc) rc = embed_mlp(c, w->embed[4], in->x + 12, 18, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true, true, true);
+            if (!rc) rc = embed_mlp(c, w->embed[2], in->edge_pos, 6, M, c.X, 768, c.X, 768, 1, nullptr, 0, 1, true, true, true);
             break;
     }
     if (rc) return rc;
 
     // ---- key-padding mask [B,N] ----------------------------------------------------------------------------
     const uint8_t* key_pad = in->mask;
-    if (net == BG_EDGEPOS && in->mask) {
+    if (varlen) key_pad = nullptr;                                // every compact row is a valid key
+    if (net == BG_EDGEPOS && in->mask && !varlen) {
         uint8_t* mexp = c.ws + c.p.off_mask;
         const size_t n = (size_t)M;
         const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
@@ -226,30 +266,39 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
+        qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint;
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
-        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
+        op.m_dev = c.m_dev; op.rows_hint = c.rows_hint;
         if ((rc = gemm(op, c.dtype, s))) return rc;
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
+        f1.m_dev = c.m_dev; f1.rows_hint = c.rows_hint;
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         f2.out_lo = c.XL; f2.res_hi = c.XH; f2.res_lo = c.XL; f2.ld_res = 768; f2.stats_out = c.stats;
+        f2.m_dev = c.m_dev; f2.rows_hint = c.rows_hint;
         if ((rc = gemm(f2, c.dtype, s))) return rc;
     }
     for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
-        if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s))) return rc;
+        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rows_hint = c.rows_hint; };
+        if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        vl(qkv);
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
-        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.X, 768, M, 768, 768, 768, BG_F32, BG_ACT_NONE, c.X, 768, 1};
+        vl(op);
         if ((rc = gemm(op, c.dtype, s))) return rc;
-        if ((rc = layernorm768(c.X, L.ln2_g, L.ln2_b, c.H, c.dtype, M, 1e-5f, 0, s))) return rc;
+        if ((rc = layernorm768(c.X, L.ln2_g, L.ln2_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev))) return rc;
         GemmArgs f1{c.H, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
+        vl(f1);
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.X, 768, M, 768, 768, 1024, BG_F32, BG_ACT_NONE, c.X, 768, 1};
+        vl(f2);
         if ((rc = gemm(f2, c.dtype, s))) return rc;
     }
 
@@ -257,11 +306,12 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // fc_out.0 reads the final-LN output from H and writes its fp32 result to R; the LN+SiLU then overwrites H.
     {
         void* hf = c.H;
-        if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s);
-        else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s);
+        if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s, c.m_dev);
+        else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s, c.m_dev);
         if (rc) return rc;
         const bg_mlp_weights& m = w->fc_out;
-        rc = embed_mlp(c, m, hf, 768, M, eps_out, m.n_out, nullptr, 0, 1, nullptr, 0, 1);
+        // (variable-length: the compact result rows are scattered into the zero-filled padded eps_out)
+        rc = embed_mlp(c, m, hf, 768, M, eps_out, m.n_out, nullptr, 0, 1, nullptr, 0, 1, false, true, false, false, false, true);
     }
     return rc;
 }

@@ -15,10 +15,10 @@ template <int OUT, bool SILU, bool SPLIT_IN = false>    // OUT: BG_F32 | BG_F16 
 __global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x, const void* __restrict__ x_lo,
                                                     const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, void* __restrict__ y, int M,
-                                                    float eps) {
+                                                    float eps, const int* __restrict__ m_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    if (row >= (m_dev ? *m_dev : M)) return;                     // compacted batch: the row count lives on the device
     float4 v[3];
     if (SPLIT_IN) {         // x = hi + lo, two 16-bit planes of dtype OUT (the denoisers' split residual stream)
         const uint2* hr = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + (size_t)row * 768);
@@ -68,19 +68,19 @@ __global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x,
 }
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps, int silu,
-                 hipStream_t s) {
+                 hipStream_t s, const int* m_dev) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
     ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_F32 ? 4.0 : 2.0)), s);
     if (y_dtype == BG_BF16) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
+        else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
     } else if (y_dtype == BG_F16) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_F16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
     } else if (y_dtype == BG_F32) {
-        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F32, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
-        else hipLaunchKernelGGL((ln768_kernel<BG_F32, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps);
+        if (silu) hipLaunchKernelGGL((ln768_kernel<BG_F32, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
+        else hipLaunchKernelGGL((ln768_kernel<BG_F32, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
     } else {
         set_error("layernorm: unsupported output dtype %d", y_dtype);
         return BG_E_DTYPE;
@@ -89,13 +89,13 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
 }
 
 int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
-                       float eps, hipStream_t s) {
+                       float eps, hipStream_t s, const int* m_dev) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
     ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * 6.0, s);
     const float* x = reinterpret_cast<const float*>(hi);
-    if (y_dtype == BG_BF16) hipLaunchKernelGGL((ln768_kernel<BG_BF16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps);
-    else if (y_dtype == BG_F16) hipLaunchKernelGGL((ln768_kernel<BG_F16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps);
+    if (y_dtype == BG_BF16) hipLaunchKernelGGL((ln768_kernel<BG_BF16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps, m_dev);
+    else if (y_dtype == BG_F16) hipLaunchKernelGGL((ln768_kernel<BG_F16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps, m_dev);
     else {
         set_error("layernorm (split input): unsupported dtype %d", y_dtype);
         return BG_E_DTYPE;

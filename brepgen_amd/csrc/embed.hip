@@ -32,17 +32,21 @@ template <int OUT, int K2>      // OUT: BG_F32 | BG_BF16 | BG_F16;  K2 = k / 2 i
 __global__ __launch_bounds__(512) void embed_ln_silu_kernel(const float* __restrict__ x, int lda, int rows,
                                                             const float* __restrict__ w0p, const float* __restrict__ b0,
                                                             const float* __restrict__ gam, const float* __restrict__ bet,
-                                                            void* __restrict__ out, float eps) {
+                                                            void* __restrict__ out, float eps,
+                                                            const int* __restrict__ m_dev, const int* __restrict__ src_row) {
     constexpr int NW = 8, TPW = 3;                                // waves per block, 32-column tiles per wave
     __shared__ float red[2][NW][32];
     __shared__ __attribute__((aligned(16))) unsigned tile[OUT == BG_F32 ? 1 : 32 * 384];      // 32 rows x 768 x 2 B
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int row0 = blockIdx.x * 32;
+    if (m_dev) rows = *m_dev;                                     // compacted batch: the row count lives on the device
+    if (row0 >= rows) return;                                     // uniform per workgroup, before any barrier
 
-    // A operand: lane supplies x[row0 + c][2*kk + h]
+    // A operand: lane supplies x[row0 + c][2*kk + h] (compacted batch: row r of the output reads x[src_row[r]])
     int arow = row0 + c;
     arow = arow < rows ? arow : rows - 1;
+    if (src_row) arow = src_row[arow];
     const float* xr = x + (size_t)arow * lda + h;
     float a[K2];
 #pragma unroll
@@ -153,16 +157,17 @@ __global__ __launch_bounds__(512) void embed_ln_silu_kernel(const float* __restr
 
 template <int OUT>
 static void launch_embed(int k2, dim3 grid, hipStream_t s, const float* x, int lda, int rows, const float* w0p,
-                         const float* b0, const float* g, const float* b, void* out, float eps) {
-    if (k2 == 3) hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 3>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps);
-    else if (k2 == 6) hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 6>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps);
-    else hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 24>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps);
+                         const float* b0, const float* g, const float* b, void* out, float eps, const int* m_dev,
+                         const int* src_row) {
+    if (k2 == 3) hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 3>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
+    else if (k2 == 6) hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 6>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
+    else hipLaunchKernelGGL((embed_ln_silu_kernel<OUT, 24>), grid, dim3(512), 0, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
 }
 
 bool embed_ln_silu_supported(int k) { return k == 6 || k == 12 || k == 48; }
 
 int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
-                  const float* b, void* out, int out_dtype, float eps, hipStream_t s) {
+                  const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev, const int* src_row) {
     if (rows <= 0) return 0;
     if (!embed_ln_silu_supported(k) || lda < k) {
         set_error("embed_ln_silu: k must be 6, 12 or 48 with lda >= k (k=%d lda=%d)", k, lda);
@@ -170,9 +175,9 @@ int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, co
     }
     const dim3 grid((rows + 31) / 32);
     ProfScope prof(PK_EMBED, 2.0 * rows * 768.0 * k, (double)rows * (4.0 * k + 768.0 * (out_dtype == BG_F32 ? 4.0 : 2.0)), s);
-    if (out_dtype == BG_BF16) launch_embed<BG_BF16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps);
-    else if (out_dtype == BG_F16) launch_embed<BG_F16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps);
-    else if (out_dtype == BG_F32) launch_embed<BG_F32>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps);
+    if (out_dtype == BG_BF16) launch_embed<BG_BF16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
+    else if (out_dtype == BG_F16) launch_embed<BG_F16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
+    else if (out_dtype == BG_F32) launch_embed<BG_F32>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
     else {
         set_error("embed_ln_silu: unsupported output dtype %d", out_dtype);
         return BG_E_DTYPE;

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     const int nblk = gridDim.x;
     const int tile = xcd_remap(blockIdx.x, nblk);
     const int m0 = (tile / nt_n) * BM, n0 = (tile % nt_n) * BN;
+    const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
+    if (m0 >= Mv) return;                                         // uniform per workgroup, before any barrier
 
     // ---- LDS-DMA source addresses (per lane), destination bases (per wave) ----
     constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;   // wave-instructions per wave per stage
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
         const int row = (wave * A_INSTR + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         int grow = m0 + row;
-        grow = grow < g.M ? grow : g.M - 1;                       // clamp: rows >= M are never stored
+        grow = grow < Mv ? grow : Mv - 1;                         // clamp: rows >= M are never stored
         a_src[j] = A + (size_t)grow * g.lda + c * 8;
     }
 #pragma unroll
@@ -241,8 +243,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     for (int it = 0; it < TM * 32 / RPI; ++it) {
         const int pr = it * RPI + rr;
         const int grow = m0 + wm * (TM * 32) + pr;
-        const bool row_ok = grow < g.M;
-        const int crow = row_ok ? grow : g.M - 1;
+        const bool row_ok = grow < Mv;
+        const int crow = row_ok ? grow : Mv - 1;
+        const int prow = g.row_map ? g.row_map[crow] : crow;      // index in the padded token layout (compacted batches)
+        const int arow1 = g.map_add ? prow : crow, arow2 = g.map_add2 ? prow : crow, orow = g.map_out ? prow : grow;
         float4 v = *reinterpret_cast<const float4*>(&patch[pr * PW + c4]);
         if (g.stats_in) {                                         // LayerNorm fold: the 16 lanes of a row share its statistics
             float2 pq = make_float2(0.f, 0.f);
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
         }
         if (vec) {
             if (g.add) {
-                const float4 a4 = *reinterpret_cast<const float4*>(g.add + (size_t)(crow / g.add_div) * g.ld_add + gcol);
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add + (size_t)(arow1 / g.add_div) * g.ld_add + gcol);
                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
             }
             if (g.res_hi) {                                       // split residual stream: x_old = hi + lo
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
                 v.x += fh[0] + fl[0]; v.y += fh[1] + fl[1]; v.z += fh[2] + fl[2]; v.w += fh[3] + fl[3];
             }
             if (g.add2) {
-                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol);
+                const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(arow2 / g.add2_div) * g.ld_add2 + gcol);
                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
             }
             if (g.stats_out) {                                    // per-64-column (sum, sum of squares) of the fp32 result
@@ -288,13 +292,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
                 uint2 hi, lo;
                 split4_16<F16>(vv, hi, lo);
-                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) = hi;
-                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out_lo) + (size_t)grow * g.ldc + gcol) = lo;
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out) + (size_t)orow * g.ldc + gcol) = hi;
+                *reinterpret_cast<uint2*>(reinterpret_cast<T*>(g.out_lo) + (size_t)orow * g.ldc + gcol) = lo;
             } else if (g.out_dtype != BG_F32)
-                *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
+                *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)orow * g.ldc + gcol) =
                     E::pack4(v.x, v.y, v.z, v.w);
             else
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)orow * g.ldc + gcol) = v;
         } else {
             if (!row_ok) continue;
             const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -303,10 +307,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
                 const int col = gcol + e;
                 if (col >= g.N) continue;
                 float o = vv[e];
-                if (g.add) o += g.add[(size_t)(grow / g.add_div) * g.ld_add + col];
-                if (g.add2) o += g.add2[(size_t)(grow / g.add2_div) * g.ld_add2 + col];
-                if (g.out_dtype != BG_F32) reinterpret_cast<T*>(g.out)[(size_t)grow * g.ldc + col] = (T)o;
-                else reinterpret_cast<float*>(g.out)[(size_t)grow * g.ldc + col] = o;
+                if (g.add) o += g.add[(size_t)(arow1 / g.add_div) * g.ld_add + col];
+                if (g.add2) o += g.add2[(size_t)(arow2 / g.add2_div) * g.ld_add2 + col];
+                if (g.out_dtype != BG_F32) reinterpret_cast<T*>(g.out)[(size_t)orow * g.ldc + col] = (T)o;
+                else reinterpret_cast<float*>(g.out)[(size_t)orow * g.ldc + col] = o;
             }
         }
     }
@@ -356,6 +360,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int h = lane >> 5;
     const int nt_n = g.N_pad / BN;
     const int G = gridDim.x;
+    const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
+    if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
     // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
     // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
     // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             int grow = m0 + a_row[j];
-            grow = grow < g.M ? grow : g.M - 1;
+            grow = grow < Mv ? grow : Mv - 1;
             a_src[j] = A + (size_t)grow * g.lda + a_chunk[j];
         }
 #pragma unroll
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     int grow = rbase + t * 16 + it * 8 + (lane >> 3);
-                    grow = grow < g.M ? grow : g.M - 1;
+                    grow = grow < Mv ? grow : Mv - 1;
                     // two 16-byte loads either way (hi / lo octets, or 8 fp32 addends): select the ADDRESSES, so the
                     // loads themselves stay unconditional and in flight together
                     const size_t o = (size_t)grow * g.ld_res + cbase + (lane & 7) * 8;
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 int grow = rbase + i * 32 + it * 8 + (lane >> 3);
-                grow = grow < g.M ? grow : g.M - 1;
+                grow = grow < Mv ? grow : Mv - 1;
                 res[buf][it] = *reinterpret_cast<const float4*>(
                     g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
             }
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         float2 st[16];
         auto load_stats = [&]() {
             int grow = rbase + lane;
-            grow = grow < g.M ? grow : g.M - 1;
+            grow = grow < Mv ? grow : Mv - 1;
             const float2* sp = reinterpret_cast<const float2*>(g.stats_in) + grow;     // part-major: [KT][M] pairs
 #pragma unroll
             for (int p = 0; p < 16; ++p)                          // K == 768 (launcher): 12 unconditional loads in flight together
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     const int prow = it * 8 + (lane >> 3), chunk = lane & 7;
                     const uint4 v = *reinterpret_cast<const uint4*>(&patch[prow * 32 + chunk * 4]);
                     const int grow = rbase + i * 32 + prow;
-                    if (grow < g.M)
+                    if (grow < Mv)
                         *reinterpret_cast<uint4*>(out + (size_t)grow * g.ldc + cbase + chunk * 8) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     const float4 p1 = *reinterpret_cast<const float4*>(&pf[prow * 64 + c8 + 4]);
                     float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
                     const int grow = rbase + t * 16 + prow, gcol = cbase + c8;
-                    const bool row_ok = grow < g.M;
+                    const bool row_ok = grow < Mv;
                     if (has_res) {
                         const float4 r0 = res[t & 1][2 * it], r1 = res[t & 1][2 * it + 1];
                         if (g.res_hi) {                           // x_old = hi + lo
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                         }
                     }
                     if (g.add2) {
-                        const int crow = row_ok ? grow : g.M - 1;
+                        const int crow = row_ok ? grow : Mv - 1;
                         const float* ap = g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol;
                         const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
                         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                             const float4 a4 = res[(i * TN + j) & 1][it];
                             v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
                         }
-                        if (grow < g.M) {
+                        if (grow < Mv) {
                             if (g.add2) {
                                 const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(grow / g.add2_div) * g.ld_add2 + gcol);
                                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
@@ -754,7 +760,7 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     }
     const int nt = m128 * n128;
     const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
-                               (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64;
+                               (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64 && g.row_map == nullptr;
     // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
     //  persistent and the generic kernel implement them, with bit-identical arithmetic)
     const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
@@ -819,9 +825,10 @@ int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s) {
     }
     // algorithmic cost: 2*M*N*K flops; bytes = operands once + output once (+ addends)
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
-    const double bytes = 2.0 * g.M * g.K + 2.0 * g.N * (double)g.K + osz * g.M * g.N +
-                         (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0) + (g.add2 ? 4.0 * (g.M / g.add2_div) * g.N : 0.0);
-    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, 2.0 * g.M * g.N * (double)g.K, bytes, s);
+    const double rows = g.rows_hint > 0 ? g.rows_hint : g.M;
+    const double bytes = 2.0 * rows * g.K + 2.0 * g.N * (double)g.K + osz * rows * g.N +
+                         (g.add ? 4.0 * (rows / g.add_div) * g.N : 0.0) + (g.add2 ? 4.0 * (rows / g.add2_div) * g.N : 0.0);
+    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, 2.0 * rows * g.N * (double)g.K, bytes, s);
     return ab_dtype == BG_F16 ? launch16<true>(g, s) : launch16<false>(g, s);
 }
 

@@ -19,11 +19,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int nt_n = (g.N + F_BN - 1) / F_BN;
     const int m0 = (blockIdx.x / nt_n) * F_BM, n0 = (blockIdx.x % nt_n) * F_BN;
+    const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
+    if (m0 >= Mv) return;
 
     // global -> LDS assignment: thread t loads 4 consecutive k of one row of A and one row of W
     const int lrow = tid >> 2, lk = (tid & 3) * 4;
     const int arow = m0 + lrow, wrow = n0 + lrow;
-    const bool a_ok = arow < g.M, w_ok = wrow < g.N_pad;
+    const bool a_ok = arow < Mv, w_ok = wrow < g.N_pad;
     const float* ap = A + (size_t)(a_ok ? arow : 0) * g.lda;
     const float* wp = W + (size_t)(w_ok ? wrow : 0) * g.K;
 
@@ -61,14 +63,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
+        if (row >= Mv) continue;
+        const int prow = g.row_map ? g.row_map[row] : row;        // this row's index in the padded token layout
+        const int orow = g.map_out ? prow : row;
         float v = acc[r] + bias;
         if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
-        if (g.add) v += g.add[(size_t)(row / g.add_div) * g.ld_add + col];
-        if (g.add2) v += g.add2[(size_t)(row / g.add2_div) * g.ld_add2 + col];
-        if (g.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(g.out)[(size_t)row * g.ldc + col] = (__bf16)v;
-        else if (g.out_dtype == BG_F16) reinterpret_cast<_Float16*>(g.out)[(size_t)row * g.ldc + col] = (_Float16)v;
-        else reinterpret_cast<float*>(g.out)[(size_t)row * g.ldc + col] = v;
+        if (g.add) v += g.add[(size_t)((g.map_add ? prow : row) / g.add_div) * g.ld_add + col];
+        if (g.add2) v += g.add2[(size_t)((g.map_add2 ? prow : row) / g.add2_div) * g.ld_add2 + col];
+        if (g.out_dtype == BG_BF16) reinterpret_cast<__bf16*>(g.out)[(size_t)orow * g.ldc + col] = (__bf16)v;
+        else if (g.out_dtype == BG_F16) reinterpret_cast<_Float16*>(g.out)[(size_t)orow * g.ldc + col] = (_Float16)v;
+        else reinterpret_cast<float*>(g.out)[(size_t)orow * g.ldc + col] = v;
     }
 }
 
@@ -116,8 +120,9 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     }
     const int nblk = ((g.M + F_BM - 1) / F_BM) * ((g.N + F_BN - 1) / F_BN);
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
-    ProfScope prof(PK_GEMM_F32, 2.0 * g.M * g.N * (double)g.K,
-                   4.0 * g.M * g.K + 4.0 * g.N * (double)g.K + osz * g.M * g.N + (g.add ? 4.0 * (g.M / g.add_div) * g.N : 0.0), s);
+    const double rows = g.rows_hint > 0 ? g.rows_hint : g.M;
+    ProfScope prof(PK_GEMM_F32, 2.0 * rows * g.N * (double)g.K,
+                   4.0 * rows * g.K + 4.0 * g.N * (double)g.K + osz * rows * g.N + (g.add ? 4.0 * (rows / g.add_div) * g.N : 0.0), s);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(nblk), dim3(256), 0, s, g);
     return launch_status("gemm_f32");
 }

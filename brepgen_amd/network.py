@@ -12,6 +12,11 @@ accumulation and fp32 LayerNorm / softmax statistics; the residual stream is kep
 epilogues (``fold_layernorm``; False restores an fp32 stream and LayerNorm kernels), and the first Linear + LayerNorm +
 SiLU of every input embed is one kernel (``fuse_embed``).  Outside autocast everything is exact fp32 (f32-input
 MFMA).  ``compute_dtype`` overrides.  The returned eps is always fp32.
+
+Variable length (``varlen``, default on): the nets that take a padding mask run only their valid tokens -- packed into
+consecutive rows on the device (csrc/compact.hip), GEMMs on sum(valid) rows, attention per sample -- and return 0 at
+padded positions; valid positions are what the dense path gives up to rounding, because the reference masks padding as
+attention keys (network.py:1196, 1283, 1390).  ``varlen = False`` computes every position like the reference.
 """
 import ctypes as C
 
@@ -89,6 +94,11 @@ class _HipDenoiser(nn.Module):
         self.cache_conditioning = True   # reuse step-invariant conditioning embeds while the inputs are unchanged
         self.fuse_embed = True           # input embeds: Linear(k) + LayerNorm + SiLU as one kernel (k = 6 / 12 / 48)
         self.fold_layernorm = True       # 16-bit dtypes: norm1 / norm2 folded into the QKV / FFN1 GEMMs, split residual
+        # Variable-length execution (nets that take a mask): only the VALID tokens run through the network (compacted on
+        # the device, no host sync); eps at padded positions is 0 where the reference returns values nobody reads
+        # (sample.py:284, 307-314).  False = dense execution, every position as the reference computes it.
+        self.varlen = True
+        self.profile_hints = None        # (valid tokens, sum of valid^2): FLOP accounting of the opt-in profiler only
         self._packs = {}
         self._workspace = None
         self._cond = None                # conditioning-embed cache entry
@@ -237,6 +247,8 @@ class _HipDenoiser(nn.Module):
         inp.mask, inp.timesteps, inp.class_label = ptr(mk), ptr(t), ptr(class_label)
         # step-invariant conditioning cache, keyed on the identity + version of the conditioning tensors
         inp.cond_cache, inp.cond_cache_valid = None, 0
+        inp.varlen = int(bool(self.varlen) and mk is not None and self.NET != BG_SURFPOS)
+        inp.rows_hint, inp.pairs_hint = (self.profile_hints if (self.profile_hints and inp.varlen) else (0.0, 0.0))
         # (never while a HIP graph is being captured: the flag would be baked into the graph, and a replay after the
         #  caller refreshed the static conditioning buffers through raw pointers would use stale embeds)
         use_cache = (self.cache_conditioning and surf_pos is not None and not self.training

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 2
+#define BG_ABI_VERSION 3
 
 typedef void* bg_stream_t;              /* hipStream_t */
 
@@ -171,7 +171,15 @@ typedef struct {
     const int64_t* class_label;  /* [B] or NULL */
     float* cond_cache;      /* optional [B*S,768] fp32: step-invariant conditioning embeds */
     int cond_cache_valid;   /* 1: reuse cond_cache, 0: (re)compute and store if cond_cache != NULL */
-    int _pad;
+    /* Variable-length execution (needs mask): the valid tokens of every sample are packed into consecutive rows, all
+     * GEMM / LayerNorm work runs on sum(valid) rows, attention runs per sample over its own rows, eps_out is the padded
+     * layout with 0 at padded positions.  Valid positions are unchanged up to rounding (a padded token is never a key
+     * of a valid query: network.py:1196, 1283, 1390); the reference computes -- and discards, sample.py:284, 307-314 --
+     * values at padded positions.  The row count stays on the device: no host synchronisation. */
+    int varlen;
+    /* expected number of valid tokens / sum over samples of valid^2, ONLY for the opt-in profiler's FLOP accounting
+     * (bg_profile_*); 0 = unknown (the profiler then books the padded sizes) */
+    double rows_hint, pairs_hint;
 } bg_denoiser_inputs;
 
 /* bytes of scratch bg_denoiser_fwd needs for these shapes */

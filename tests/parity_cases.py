@@ -241,25 +241,29 @@ NETS = {"SurfPosNet": bga.SurfPosNet, "SurfZNet": bga.SurfZNet, "EdgePosNet": bg
 MANIFEST = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
 
 
-def build_net(net, seed, use_cf, dtype):
+def build_net(net, seed, use_cf, dtype, varlen=False):
+    """varlen=False: dense execution (every position as the reference computes it) -- what the position-exact parity
+    tests check; varlen=True: the product default (valid tokens only, 0 at padded positions)."""
     sd = orc.seeded_state_dict(net, seed, use_cf)
     m = NETS[net](use_cf)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
     m.compute_dtype = dtype
+    m.varlen = varlen
     return m, sd
 
 
-def golden_case(name, dtype):
+def golden_case(name, dtype, varlen=False):
     """HIP denoiser vs the golden output written by the reference's own class (tests/golden/gen_golden.py)."""
     meta = MANIFEST["cases"][name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     args = [torch.from_numpy(z[k]).to(DEV) if k in z.files else None for k in meta["args"]]
-    m, _ = build_net(meta["net"], meta["weight_seed"], meta["use_cf"], dtype)
+    m, _ = build_net(meta["net"], meta["weight_seed"], meta["use_cf"], dtype, varlen)
     with torch.no_grad():
         got = m(*args)
     want = torch.from_numpy(z["out"])
     e = _err(got, want)
+    e["got"] = got.cpu()
     mask_key = "surf_mask" if "surf_mask" in meta["args"] else ("mask" if "mask" in meta["args"] else None)
     if mask_key is not None and meta["net"] != "EdgePosNet":
         valid = ~torch.from_numpy(z[mask_key])
@@ -296,9 +300,9 @@ def synth_inputs(net, B, S, E, use_cf, seed=1234):
     return [R(B, S, E, 18), t, R(B, S, E, 6).clamp(-3, 3), R(B, S, 6).clamp(-3, 3), R(B, S, 48), em, cl]
 
 
-def oracle_case(net, B, S, E, dtype, use_cf=False, seed=7):
+def oracle_case(net, B, S, E, dtype, use_cf=False, seed=7, varlen=False):
     """HIP denoiser vs the CPU oracle on seeded inputs at a size the oracle finishes in seconds."""
-    m, sd = build_net(net, seed, use_cf, dtype)
+    m, sd = build_net(net, seed, use_cf, dtype, varlen)
     args = synth_inputs(net, B, S, E, use_cf)
     with torch.no_grad():
         want = orc.FORWARD[net](sd, *args)
@@ -306,10 +310,12 @@ def oracle_case(net, B, S, E, dtype, use_cf=False, seed=7):
     e = _err(got, want)
     mask = args[3] if net == "SurfZNet" else (args[4] if net == "EdgePosNet" else (args[5] if net == "EdgeZNet" else None))
     if mask is not None:
-        valid = ~mask
+        valid = ~mask if net != "EdgePosNet" else (~mask)[:, :, None].expand(B, S, E)
         e["max_abs_valid"] = float((got.cpu() - want)[valid].abs().max())
+        e["padded_absmax"] = float(got.cpu()[~valid].abs().max()) if bool((~valid).any()) else 0.0
     else:
         e["max_abs_valid"] = e["max_abs"]
+        e["padded_absmax"] = 0.0
     return e
 
 

@@ -180,3 +180,71 @@ def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
         for k in want:
             assert got[r][k].shape == want[k].shape and got[r][k].dtype == want[k].dtype, (r, k)
             assert torch.equal(got[r][k], want[k]), f"rank {r} tensor {k}"
+
+
+# ---- variable-length execution (valid tokens only) ---------------------------------------------------------------------
+VL_CASES = [("SurfZNet", 5, 60, 1, False), ("SurfZNet", 3, 17, 1, True), ("EdgePosNet", 3, 8, 20, False),
+            ("EdgeZNet", 2, 7, 30, False), ("EdgeZNet", 2, 4, 40, True), ("EdgePosNet", 2, 30, 12, True)]
+
+
+def _valid(net, args, B, S, E):
+    if net == "SurfZNet":
+        return ~args[3]
+    if net == "EdgePosNet":
+        return (~args[4])[:, :, None].expand(B, S, E)
+    return ~args[5]
+
+
+@pytest.mark.parametrize("net,B,S,E,cf", VL_CASES)
+@pytest.mark.parametrize("dt", [F32, BF16, F16])
+def test_varlen_equals_dense_on_valid_tokens_and_zero_elsewhere(pc, net, B, S, E, cf, dt):
+    m, _ = pc.build_net(net, 33, cf, dt, varlen=False)
+    args = pc.synth_inputs(net, B, S, E, cf)
+    valid = _valid(net, args, B, S, E).cuda()
+    dargs = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    with torch.no_grad():
+        dense = m(*dargs)
+        m.varlen = True
+        vl = m(*dargs)
+    assert torch.isfinite(vl).all()
+    assert float(vl[~valid].abs().max()) == 0.0 if bool((~valid).any()) else True     # padded positions: exactly 0
+    d = float((vl - dense)[valid].abs().max())
+    # fp32: same GEMM rows bit for bit, only the softmax key order changes; 16-bit: two roundings of the same quantity
+    assert d < (1e-5 if dt == F32 else 3e-2), d
+
+
+@pytest.mark.parametrize("name", ["surfz_b3_n60", "surfz_cf_b2_n17", "edgepos_b2_s6_e5", "edgez_b2_s7_e9", "edgez_cf_b2_s4_e40"])
+def test_varlen_fp32_vs_reference_golden(pc, name):
+    e = pc.golden_case(name, F32, varlen=True)
+    assert e["finite"] and e["max_abs_valid"] < 1e-5          # north_star fp32 bound, on the tokens the reference uses
+
+
+def test_varlen_vs_oracle_and_single_valid_token(pc):
+    e = pc.oracle_case("EdgeZNet", 1, 10, 20, BF16, varlen=True)
+    assert e["max_abs_valid"] < 4e-2 and e["padded_absmax"] == 0.0
+    e = pc.oracle_case("EdgePosNet", 2, 8, 20, F32, use_cf=True, varlen=True)
+    assert e["max_abs_valid"] < 1e-5 and e["padded_absmax"] == 0.0
+    # one sample with a single valid face, one with all faces valid
+    m, sd = pc.build_net("SurfZNet", 8, False, F32, varlen=True)
+    from oracle import denoisers as orc
+    args = pc.synth_inputs("SurfZNet", 3, 33, 1, False)
+    args[3][0, 1:] = True
+    args[3][0, 0] = False
+    args[3][1, :] = False
+    with torch.no_grad():
+        want = orc.surfz_forward(sd, *args)
+        got = m(*[a.cuda() if torch.is_tensor(a) else a for a in args]).cpu()
+    valid = ~args[3]
+    assert float((got - want)[valid].abs().max()) < 1e-5 and float(got[~valid].abs().max()) == 0.0
+
+
+def test_varlen_batch_row_equals_sample_alone(pc):
+    """bf16, BASELINE configs[1] shape: per-sample independence survives the compaction bit for bit (a sample's rows
+    start at its own offset; GEMM rows and per-sample attention tiles do not depend on the neighbours)."""
+    m, _ = pc.build_net("SurfZNet", 5, False, BF16, varlen=True)
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfZNet", 512, 60, 1, False)]
+    with torch.no_grad():
+        full = m(*args)
+        for b in (0, 255, 511):
+            one = m(args[0][b:b + 1].contiguous(), args[1], args[2][b:b + 1].contiguous(), args[3][b:b + 1].contiguous(), None)
+            assert torch.equal(one[0], full[b])
