@@ -128,6 +128,65 @@ def cpu_baseline(steps=3, warmup=1):
             "calibration_s_per_sample_step": {str(k): round(v, 3) for k, v in calib.items()}}
 
 
+def edge_net_extra(dev, evals=2):
+    """Reported BESIDE the headline (never part of `value`): one eps-evaluation of the edge nets at the shapes of
+    BASELINE configs[2] / configs[3] -- where 98 % of the cascade's FLOPs are -- with their own roofline.
+    Masks per SURVEY 8(d): valid faces per sample ~ U{8..S}, valid edges per valid face ~ U{3..E}."""
+    import brepgen_amd as bga
+    from brepgen_amd import _lib
+    out = []
+    for name, cls, B, S, E, c_tok in (("EdgeZNet cfg3 DeepCAD [256,60,30,18] bf16", bga.EdgeZNet, 256, 60, 30, 4.78e6),
+                                       ("EdgePosNet cfg4 ABC [512,100,40,6] bf16 (one rank's 512 samples)", bga.EdgePosNet, 512, 100, 40, 2.38e6)):
+        g = torch.Generator().manual_seed(99)
+        torch.manual_seed(1)
+        net = cls(False).to(dev).eval()
+        net.compute_dtype = torch.bfloat16
+        nf = torch.randint(8, S + 1, (B,), generator=g)
+        smask = torch.arange(S)[None] >= nf[:, None]                                     # [B,S] True = padded face
+        pos = torch.randn(B, S, 6, generator=g).clamp(-3, 3).to(dev)
+        sz = torch.randn(B, S, 48, generator=g).to(dev)
+        t = torch.tensor([249], device=dev)
+        if cls is bga.EdgeZNet:
+            ne = torch.randint(3, E + 1, (B, S), generator=g)
+            emask = (torch.arange(E)[None, None] >= ne[:, :, None]) | smask[:, :, None]     # [B,S,E]
+            ntok = (~emask).sum((1, 2)).double()
+            args = (torch.randn(B, S, E, 18, generator=g).to(dev), t, torch.randn(B, S, E, 6, generator=g).clamp(-3, 3).to(dev),
+                    pos, sz, emask.to(dev), None)
+        else:
+            ntok = (nf * E).double()
+            args = (torch.randn(B, S, E, 6, generator=g).clamp(-3, 3).to(dev), t, pos, sz, smask.to(dev), None)
+        N = S * E
+        f_dense = B * (algorithmic_flops_per_sample_eval(N, c_tok) + S * 2.44e6)
+        f_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), c_tok) for n in ntok)) + B * S * 2.44e6
+        net.profile_hints = (float(ntok.sum()), float((ntok * ntok).sum()))
+        row = {"workload": name, "tokens_per_sample": N, "valid_tokens_mean": round(float(ntok.mean()), 1),
+               "algorithmic_tflop_per_eval": round(f_dense / 1e12, 2), "executed_tflop_per_eval": round(f_exec / 1e12, 2)}
+        with torch.no_grad():
+            for mode in ("varlen", "dense"):
+                net.varlen = mode == "varlen"
+                net(*args)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(evals):
+                    net(*args)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / evals
+                fl = f_exec if net.varlen else f_dense
+                row[mode] = {"ms_per_eval": round(dt * 1e3, 2), "executed_tflops": round(fl / dt / 1e12, 1),
+                             "frac_of_mfma_peak": round(fl / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            net.varlen = True
+            with _lib.profile() as prof:
+                net(*args)
+            row["kernels_varlen"] = {r["kernel"]: {"launches": r["launches"], "total_ms": round(r["total_ms"], 3),
+                                                   "tflops": round(r["flops"] / r["total_ms"] / 1e9, 1) if r["flops"] else None,
+                                                   "frac_of_mfma_peak": round(r["flops"] / r["total_ms"] / 1e9 / MFMA_PEAK_TFLOPS, 4) if r["flops"] else None}
+                                     for r in prof.rows if r["total_ms"] > 0.05}
+        out.append(row)
+        del net, args
+        torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     written by tools/pmc_summary.py: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2
@@ -261,6 +320,8 @@ def main():
         extra["dense_execution"] = {"ms_per_step": round(1e3 * d_el / args.steps, 4),
                                     "steps_per_s_per_gpu": round(args.steps / d_el, 3)}
         net.varlen, net.profile_hints = True, hints
+    if world == 1 and rank == 0 and not args.no_extra:
+        extra["edge_nets"] = edge_net_extra(dev)
 
     roofline = None
     breakdown = None

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "bg_attn_varlen_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "bg_compact_rows": (C.c_int, [u8p, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_denoiser_fwd": (C.c_int, [C.POINTER(DenoiserWeights), C.POINTER(DenoiserInputs), fp, vp, C.c_size_t, vp]),
     "bg_embed_mlp_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),

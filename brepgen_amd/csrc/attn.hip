@@ -203,6 +203,265 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long sequences (N > 64: the edge nets, 1800 / 2400 / 4000 tokens, where attention is 40-60 % of the FLOPs).
+//
+//   * one workgroup = 4 waves = 128 queries of one (sample, head); 1-D grid walked XCD-aware so the ~15-32 query blocks
+//     of a (sample, head) run on ONE XCD and its K/V (0.5-1 MB) is fetched into that L2 once;
+//   * K and V tiles (64 keys x 128 B each) arrive by LDS-DMA into a 2-stage ring: tile t+1 is in flight while tile t is
+//     computed, counted by vmcnt, ONE barrier per tile; both images are row-major with a 16-byte XOR swizzle applied on
+//     the DMA source address (K: chunk ^= (key >> 1) & 7 for the ds_read_b128 fragment reads; V: chunk ^= ((key >> 1) & 1)
+//     << 2, i.e. 32-byte granularity, for the transpose reads);
+//   * V is consumed straight from its row-major image with ds_read_b64_tr_b16 (the hardware transpose read): a lane
+//     supplies the address of 4 consecutive d of one key and receives 4 consecutive KEYS of one d -- the V^T fragment
+//     of O^T = V^T P^T -- so the scalar transposing LDS writes of the short-sequence kernel are gone;
+//   * scores transposed as in the short kernel (S^T = K Q^T: a lane owns 2 x 16 keys of ONE query), both 32-key
+//     sub-tiles of a tile share one softmax pass: max by v_max3 chains + one v_permlane32_swap, exp as a single
+//     v_fma + v_exp_f32 per score (base-2, log2(e) folded into the fma), the O / l rescale only when the running max
+//     of some query of the wave grew by more than 3 (deferred maximum: P <= e^3 in the meantime, harmless in 16-bit
+//     floating point whose relative precision does not depend on scale);
+//   * key tiles beyond the last valid key of the sample are never visited; the mask bias is applied only in tiles that
+//     contain a masked key (a per-tile flag), so compacted (variable-length) batches pay for masking in their tail tile only.
+// MFMA-bound in principle; with d_head = 64 the softmax VALU work per MFMA is twice that of a d = 128 head, which is
+// what bounds the achievable fraction of the matrix peak here.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short v4s_t;
+
+// LDS-DMA issued from inline asm (1 KiB per wave-instruction: lane l's 16 bytes land at lds_wave_base + 16 l).  hipcc makes
+// the first ds_read_b64_tr_b16 after a *builtin* LDS-DMA wait for vmcnt(0) -- it cannot tell that the transpose read and the
+// in-flight DMA touch different ring stages -- which would serialise the next tile's fetch with this tile's P V product.
+// Hidden in asm, the DMA is ordered by hand: counted vmcnt at the loop head, then the workgroup barrier, then the reads.
+__device__ __forceinline__ void dma16_asm(const void* gsrc, void* lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+constexpr int AL_MAX_N = 4096;       // longest sequence the long kernel stages a mask for (ABC edge nets: 4000)
+
+template <bool F16>
+__global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
+                                                             void* __restrict__ out_, int B, int N, int nqb,
+                                                             const int* __restrict__ offsets) {
+    using E = AElem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    constexpr int STAGE = 2 * 64 * 128;                  // K tile + V tile
+    // ONE LDS object (a second one makes hipcc drain the DMA queue before every LDS read): ring | key flags | tile flags
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE + AL_MAX_N + 64 + 16];
+    unsigned char* kp = lds + 2 * STAGE;                 // [AL_MAX_N] 1 = this key is masked / beyond the sequence
+    unsigned char* tflag = kp + AL_MAX_N;                // [64] tile t contains such a key
+    int* nk_sh = reinterpret_cast<int*>(tflag + 64);     // [4] per-wave "last valid key + 1"
+    const T* __restrict__ qkv = reinterpret_cast<const T*>(qkv_);
+    T* __restrict__ out = reinterpret_cast<T*>(out_);
+
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware walk: consecutive logical ids (the query blocks of one (sample, head)) share an XCD
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = L % nqb, head = (L / nqb) % BG_N_HEAD, b = L / (nqb * BG_N_HEAD);
+    size_t row_base = (size_t)b * N;
+    if (offsets) {                                       // compacted batch: rows offsets[b] .. offsets[b+1]-1, all valid keys
+        row_base = (size_t)offsets[b];
+        N = offsets[b + 1] - offsets[b];
+        key_pad = nullptr;
+    }
+    if (qb * 128 >= N) return;                           // uniform per workgroup, before any barrier
+    const T* base = qkv + row_base * QKV_LD + head * 64;
+    const int q0 = qb * 128 + wave * 32;
+
+    // ---- key flags of the whole sample into LDS (once), last valid key, per-tile "has a masked key" flags ----
+    const int nkt_all = (N + 63) / 64;
+    int last = 0;
+    for (int k = tid; k < nkt_all * 64; k += 256) {
+        const bool dead = k >= N || (key_pad != nullptr && key_pad[row_base + k] != 0);
+        kp[k] = dead ? 1 : 0;
+        last = dead ? last : k + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if (lane == 0) nk_sh[wave] = last;
+    __syncthreads();
+    const int n_keys = max(max(nk_sh[0], nk_sh[1]), max(nk_sh[2], nk_sh[3]));
+    const int nkt = (n_keys + 63) / 64;                  // key tiles beyond the last valid key are never visited
+    if (tid < nkt) {
+        const uint4* w = reinterpret_cast<const uint4*>(kp + tid * 64);
+        const uint4 a = w[0], b4 = w[1], c = w[2], d = w[3];
+        tflag[tid] = ((a.x | a.y | a.z | a.w | b4.x | b4.y | b4.z | b4.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) != 0u) ? 1 : 0;
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane = (query l & 31, k-chunk h) per 16-wide slice of d ----
+    V8 qf[4];
+    {
+        int qrow = q0 + (lane & 31);
+        qrow = qrow < N ? qrow : N - 1;
+        const T* qp = base + (size_t)qrow * QKV_LD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + (ks * 2 + h) * 8);
+        // have hipcc wait for these loads HERE: a register load still pending at the loop head would make it drain the
+        // whole VMEM queue -- including the next tile's DMA -- in every iteration of the tile loop
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+    }
+    __syncthreads();                                     // tflag visible
+
+    // ---- DMA: wave w moves K pieces 2w, 2w+1 and V pieces 2w, 2w+1 of a tile (a piece = 8 keys x 128 B) ----
+    const int prow = lane >> 3, pch = lane & 7;
+    auto issue_tile = [&](int t, int st) {
+        unsigned char* kbase = lds + st * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave * 2 + j;
+            const int row = piece * 8 + prow;            // key row inside the tile
+            int key = t * 64 + row;
+            key = key < N ? key : N - 1;
+            const T* src = base + (size_t)key * QKV_LD;
+            const int kc = pch ^ ((row >> 1) & 7);
+            const int vc = pch ^ (((row >> 1) & 1) << 2);
+            dma16_asm(src + BG_D_MODEL + kc * 8, kbase + piece * 1024);
+            dma16_asm(src + 2 * BG_D_MODEL + vc * 8, kbase + 64 * 128 + piece * 1024);
+        }
+    };
+
+    // K fragment offsets (A operand of S^T): key row l & 31 of each 32-key sub-tile, 16-byte chunk ks*2+h, swizzled
+    int k_off[2], k_sw[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int row = sub * 32 + (lane & 31);
+        k_off[sub] = row * 128;
+        k_sw[sub] = (row >> 1) & 7;
+    }
+    // V^T fragment addresses for the transpose read: 16-lane group g = lane >> 4 covers d columns (g & 1) * 16 .. +15 of
+    // the 32-row d tile and the keys of k-chunk h = g >> 1; lane i of the group supplies the address of key (i >> 2),
+    // d sub-chunk (i & 3) * 4 and receives 4 consecutive keys of d column i.
+    const int gi = lane & 15, gg = lane >> 4;
+    const int v_key0 = 4 * (gg >> 1) + (gi >> 2);        // + 32*sub + 16*sl (+ 8 for the second read)
+    const int v_col = (gg & 1) * 16 + (gi & 3) * 4;      // + 32*dt   (16-bit elements)
+    // byte offset of (key0 + 32*sub + 16*sl [+ 8], col + 32*dt) in the swizzled V image.  (key >> 1) & 1 depends only on
+    // bit 1 of v_key0 for every such key, so the swizzle term is a per-lane constant
+    const int v_swz = ((v_key0 >> 1) & 1) << 2;
+    int v_off[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int col = dt * 32 + v_col;
+        v_off[dt] = v_key0 * 128 + (((col >> 3) ^ v_swz) << 4) + (col & 7) * 2;
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    if (nkt > 0) issue_tile(0, 0);
+    for (int t = 0; t < nkt; ++t) {
+        const int st = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t (issued one tile ago) landed
+        __builtin_amdgcn_s_barrier();                             // everybody's did; stage st^1 is free again
+        if (t + 1 < nkt) issue_tile(t + 1, st ^ 1);
+        const unsigned char* kt_ = lds + st * STAGE;
+        const unsigned char* vt_ = kt_ + 64 * 128;
+
+        // ---- S^T = K Q^T for both 32-key sub-tiles ----
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const V8 kf = *reinterpret_cast<const V8*>(kt_ + k_off[sub] + (((ks * 2 + h) ^ k_sw[sub]) << 4));
+                s[sub] = E::mfma(kf, qf[ks], s[sub]);
+            }
+        }
+        // register r of sub-tile sub <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
+        if (tflag[t]) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const unsigned w = *reinterpret_cast<const unsigned*>(kp + t * 64 + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        s[sub][4 * g4 + e] = ((w >> (8 * e)) & 0xffu) ? -INFINITY : s[sub][4 * g4 + e];
+                }
+        }
+        float mloc = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
+        // deferred maximum: rescale only when some query's maximum grew by more than 3 (or at its first valid tile)
+        if (!__all(mloc <= m_run + 3.0f)) {
+            const float m_new = fmaxf(m_run, mloc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = ((m_run == -INFINITY) ? 0.f : m_run) * LOG2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[sub][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][r], LOG2E, -mc));
+                psum += s[sub][r];
+            }
+        l_run += psum;
+
+        // ---- O^T += V^T P^T: per 16-key slice the P^T fragment is the lane's own score registers, the V^T fragment two
+        // transpose reads in the same key order (keys 4h..4h+3 and 8+4h..8+4h+3 of the slice) ----
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                V8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = (T)s[sub][8 * sl + e];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const unsigned char* pa = vt_ + v_off[dt] + (sub * 32 + sl * 16) * 128;
+                    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)pa);
+                    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(pa + 8 * 128));
+                    union { v4s_t s4[2]; V8 v; } va;
+                    va.s4[0] = lo; va.s4[1] = hi;
+                    o[dt] = E::mfma(va.v, pb, o[dt]);
+                }
+            }
+    }
+
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run), __builtin_bit_cast(unsigned, l_run), false, false);
+        l_run = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+    }
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    const int q = q0 + (lane & 31);
+    if (q < N) {
+        T* op = out + (row_base + q) * BG_D_MODEL + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = dt * 32 + 8 * g4 + 4 * h;
+                V4 pk;
+                pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
+                pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<V4*>(op + d) = pk;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fp32 attention: one wave per (b, head, query).  Scores for keys lane, lane+64, ... in registers/LDS,
 // accurate expf, then lane = d for the P V product.  Parity mode only.
 // ------------------------------------------------------------------------------------------------
@@ -259,14 +518,14 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const float* __restrict__
 }
 
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
-              const int* offsets, double pairs_hint) {
+              const int* offsets, double pairs_hint, double rows_hint) {
     if (B <= 0 || N <= 0) return 0;
     const double es = dtype == BG_F32 ? 4.0 : 2.0;
     // algorithmic: QK^T + PV over all heads, no mask discount; bytes: qkv read once, out written once
     // (compacted batch: pairs_hint = expected sum over samples of n_b^2, for the opt-in profiler only)
     const double pairs = (offsets && pairs_hint > 0) ? pairs_hint : (double)B * N * N;
     ProfScope prof(dtype == BG_F32 ? PK_ATTN_F32 : PK_ATTN_BF16, 4.0 * BG_N_HEAD * pairs * BG_D_HEAD,
-                   es * (pairs / N) * (QKV_LD + BG_D_MODEL), s);
+                   es * ((offsets && rows_hint > 0) ? rows_hint : (double)B * N) * (QKV_LD + BG_D_MODEL), s);
     if (dtype == BG_BF16 || dtype == BG_F16) {
         const bool f16 = dtype == BG_F16;
         if (N <= 32) {
@@ -277,10 +536,15 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             const dim3 grid(1, BG_N_HEAD / 2, B);
             if (f16) hipLaunchKernelGGL((attn16_kernel<2, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
             else hipLaunchKernelGGL((attn16_kernel<2, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
-        } else {
+        } else if (g_tune[6] == 1 || N > AL_MAX_N) {               // A/B baseline / very long sequences: the round-1 single-buffered kernel
             const dim3 grid((N + 127) / 128, BG_N_HEAD, B);
             if (f16) hipLaunchKernelGGL((attn16_kernel<4, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
             else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
+        } else {
+            const int nqb = (N + 127) / 128;
+            const dim3 grid(nqb * BG_N_HEAD * B);
+            if (f16) hipLaunchKernelGGL((attn16_long_kernel<true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            else hipLaunchKernelGGL((attn16_long_kernel<false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
         }
         return launch_status("attn16");
     }
@@ -308,4 +572,12 @@ extern "C" int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, i
     BG_REQUIRE(qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_attn_fwd: null pointer or negative size");
     BG_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, BG_E_ALIGN, "bg_attn_fwd: 16-byte alignment");
     return bg::attention(qkv, key_pad, out, B, N, dtype, (hipStream_t)stream, nullptr, 0.0);
+}
+
+extern "C" int bg_attn_varlen_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
+                                  const int* offsets, bg_stream_t stream) {
+    BG_REQUIRE(qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_attn_varlen_fwd: null pointer or negative size");
+    BG_REQUIRE(!(offsets && key_pad), BG_E_ARG, "bg_attn_varlen_fwd: a compacted batch has no padded keys (key_pad must be NULL)");
+    BG_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, BG_E_ALIGN, "bg_attn_varlen_fwd: 16-byte alignment");
+    return bg::attention(qkv, key_pad, out, B, N, dtype, (hipStream_t)stream, offsets, 0.0);
 }

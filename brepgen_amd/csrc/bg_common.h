@@ -179,20 +179,20 @@ int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s);   // ab_dtype: B
 int gemm(const GemmArgs& g, int ab_dtype, hipStream_t s);
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps,
-                 int silu, hipStream_t s, const int* m_dev = nullptr);
+                 int silu, hipStream_t s, const int* m_dev = nullptr, double rows_hint = 0.0);
 // same, input rows given as the split pair x = hi + lo (16-bit planes of dtype y_dtype)
 int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
-                       float eps, hipStream_t s, const int* m_dev = nullptr);
+                       float eps, hipStream_t s, const int* m_dev = nullptr, double rows_hint = 0.0);
 // h = SiLU(LayerNorm(x W0^T + b0)) for k in {6, 12, 48}; w0p = W0 in MFMA operand order (embed.hip)
 bool embed_ln_silu_supported(int k);
 // (m_dev / src_row: compacted batches -- *m_dev rows exist, row r reads x[src_row[r]])
 int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
                   const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev = nullptr,
-                  const int* src_row = nullptr);
+                  const int* src_row = nullptr, double rows_hint = 0.0);
 // offsets != null: compacted batch -- sample b owns qkv / out rows offsets[b] .. offsets[b+1]-1 (<= N of them, all valid
 // keys; key_pad is ignored); otherwise sample b owns rows b*N .. b*N+N-1 and key_pad marks the padded keys.
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
-              const int* offsets = nullptr, double pairs_hint = 0.0);
+              const int* offsets = nullptr, double pairs_hint = 0.0, double rows_hint = 0.0);
 // valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
 // covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),
 // src_row [B * n_mask * rep]: padded-layout index of every compact row, in order.

@@ -90,3 +90,9 @@ int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, 
 }
 
 }  // namespace bg
+
+extern "C" int bg_compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, bg_stream_t stream) {
+    BG_REQUIRE(mask && offsets && src_row, BG_E_ARG, "bg_compact_rows: null pointer");
+    BG_REQUIRE(B > 0 && n_mask > 0 && rep > 0, BG_E_SHAPE, "bg_compact_rows: empty shape");
+    return bg::compact_rows(mask, B, n_mask, rep, offsets, src_row, (hipStream_t)stream);
+}

@@ -123,7 +123,7 @@ static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, in
     if (m.w0_mfma && m.w0_dtype == BG_F32 && embed_ln_silu_supported(m.k_in)) {
         // input embeds (k = 6 / 12 / 48): Linear + LayerNorm + SiLU in one kernel, nothing but the result written
         rc = embed_ln_silu(reinterpret_cast<const float*>(x), lda, rows, m.k_in, m.w0_mfma, m.b0, m.ln_g, m.ln_b, c.H,
-                           c.dtype, 1e-5f, c.s, m_dev, (vl && gather) ? c.src_row : nullptr);
+                           c.dtype, 1e-5f, c.s, m_dev, (vl && gather) ? c.src_row : nullptr, hint);
         if (rc) return rc;
     } else {
         BG_REQUIRE(!(vl && gather), BG_E_ARG, "bg_denoiser_fwd: variable-length execution needs the fused input embeds (w0_mfma)");
@@ -133,7 +133,7 @@ static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, in
         g1.m_dev = m_dev; g1.rows_hint = hint;
         rc = gemm(g1, m.w0_dtype, c.s);
         if (rc) return rc;
-        rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s, m_dev);
+        rc = layernorm768(t0, m.ln_g, m.ln_b, c.H, c.dtype, rows, 1e-5f, /*silu=*/1, c.s, m_dev, hint);
         if (rc) return rc;
     }
     GemmArgs g2{c.H, 768, m.w3, m.b3, out, ldc, rows, m.n_out, m.n_out_pad, 768, BG_F32, BG_ACT_NONE, add, ld_add,
@@ -268,7 +268,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
         qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint;
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
-        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
         op.m_dev = c.m_dev; op.rows_hint = c.rows_hint;
@@ -285,15 +285,15 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
         auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rows_hint = c.rows_hint; };
-        if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev))) return rc;
+        if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         vl(qkv);
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
-        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint))) return rc;
+        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.X, 768, M, 768, 768, 768, BG_F32, BG_ACT_NONE, c.X, 768, 1};
         vl(op);
         if ((rc = gemm(op, c.dtype, s))) return rc;
-        if ((rc = layernorm768(c.X, L.ln2_g, L.ln2_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev))) return rc;
+        if ((rc = layernorm768(c.X, L.ln2_g, L.ln2_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint))) return rc;
         GemmArgs f1{c.H, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         vl(f1);
         if ((rc = gemm(f1, c.dtype, s))) return rc;
@@ -306,8 +306,8 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // fc_out.0 reads the final-LN output from H and writes its fp32 result to R; the LN+SiLU then overwrites H.
     {
         void* hf = c.H;
-        if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s, c.m_dev);
-        else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s, c.m_dev);
+        if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s, c.m_dev, c.rows_hint);
+        else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint);
         if (rc) return rc;
         const bg_mlp_weights& m = w->fc_out;
         // (variable-length: the compact result rows are scattered into the zero-filled padded eps_out)

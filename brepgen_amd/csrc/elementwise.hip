@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void ln768_kernel(const float* __restrict__ x,
 }
 
 int layernorm768(const float* x, const float* g, const float* b, void* y, int y_dtype, int M, float eps, int silu,
-                 hipStream_t s, const int* m_dev) {
+                 hipStream_t s, const int* m_dev, double rows_hint) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
-    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * (4.0 + (y_dtype == BG_F32 ? 4.0 : 2.0)), s);
+    ProfScope prof(PK_LAYERNORM, 0.0, (rows_hint > 0 ? rows_hint : (double)M) * 768 * (4.0 + (y_dtype == BG_F32 ? 4.0 : 2.0)), s);
     if (y_dtype == BG_BF16) {
         if (silu) hipLaunchKernelGGL((ln768_kernel<BG_BF16, true>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
         else hipLaunchKernelGGL((ln768_kernel<BG_BF16, false>), grid, block, 0, s, x, (const void*)nullptr, g, b, y, M, eps, m_dev);
@@ -89,10 +89,10 @@ int layernorm768(const float* x, const float* g, const float* b, void* y, int y_
 }
 
 int layernorm768_split(const void* hi, const void* lo, const float* g, const float* b, void* y, int y_dtype, int M,
-                       float eps, hipStream_t s, const int* m_dev) {
+                       float eps, hipStream_t s, const int* m_dev, double rows_hint) {
     if (M <= 0) return 0;
     dim3 grid((M + 3) / 4), block(256);
-    ProfScope prof(PK_LAYERNORM, 0.0, (double)M * 768 * 6.0, s);
+    ProfScope prof(PK_LAYERNORM, 0.0, (rows_hint > 0 ? rows_hint : (double)M) * 768 * 6.0, s);
     const float* x = reinterpret_cast<const float*>(hi);
     if (y_dtype == BG_BF16) hipLaunchKernelGGL((ln768_kernel<BG_BF16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps, m_dev);
     else if (y_dtype == BG_F16) hipLaunchKernelGGL((ln768_kernel<BG_F16, false, true>), grid, block, 0, s, x, lo, g, b, y, M, eps, m_dev);

@@ -167,14 +167,15 @@ static void launch_embed(int k2, dim3 grid, hipStream_t s, const float* x, int l
 bool embed_ln_silu_supported(int k) { return k == 6 || k == 12 || k == 48; }
 
 int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
-                  const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev, const int* src_row) {
+                  const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev, const int* src_row, double rows_hint) {
     if (rows <= 0) return 0;
     if (!embed_ln_silu_supported(k) || lda < k) {
         set_error("embed_ln_silu: k must be 6, 12 or 48 with lda >= k (k=%d lda=%d)", k, lda);
         return BG_E_SHAPE;
     }
     const dim3 grid((rows + 31) / 32);
-    ProfScope prof(PK_EMBED, 2.0 * rows * 768.0 * k, (double)rows * (4.0 * k + 768.0 * (out_dtype == BG_F32 ? 4.0 : 2.0)), s);
+    const double prows = rows_hint > 0 ? rows_hint : (double)rows;
+    ProfScope prof(PK_EMBED, 2.0 * prows * 768.0 * k, prows * (4.0 * k + 768.0 * (out_dtype == BG_F32 ? 4.0 : 2.0)), s);
     if (out_dtype == BG_BF16) launch_embed<BG_BF16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
     else if (out_dtype == BG_F16) launch_embed<BG_F16>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);
     else if (out_dtype == BG_F32) launch_embed<BG_F32>(k / 2, grid, s, x, lda, rows, w0p, b0, g, b, out, eps, m_dev, src_row);

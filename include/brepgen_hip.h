@@ -109,6 +109,16 @@ int bg_embed_ln_silu_fwd(const float* x, int lda, int rows, int k, const float* 
  * (the reference yields NaN there; the pipeline never produces such a sample, sample.py:163,261). */
 int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
                 bg_stream_t stream);
+/* The same over a COMPACTED batch (variable-length execution): offsets int32 [B+1] on the device, sample b owns rows
+ * offsets[b] .. offsets[b+1]-1 of qkv / out (at most N of them, every one a valid key; key_pad must then be NULL).
+ * offsets == NULL is bg_attn_fwd. */
+int bg_attn_varlen_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
+                       const int* offsets, bg_stream_t stream);
+/* Valid-token compaction behind the variable-length execution (csrc/compact.hip): mask uint8 [B, n_mask] (1 = padded),
+ * each entry covering `rep` consecutive tokens (EdgePosNet: one entry per face, rep = E).  Writes offsets int32 [B+1]
+ * (offsets[B] = number of valid tokens; it stays on the device) and src_row int32 [B*n_mask*rep]: the padded-layout index of
+ * every compact row, in order (entries past offsets[B] are not written). */
+int bg_compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, bg_stream_t stream);
 
 /* ---- whole denoiser -------------------------------------------------------------------- */
 

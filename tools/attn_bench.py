@@ -1,20 +1,55 @@
 #!/usr/bin/env python
-import os, sys
+"""Attention micro-benchmark: round-1 kernel (bg_tune key 6 = 1) vs the long-sequence kernel, interleaved in one process
+(dense / ragged key mask / compacted variable-length batch), at the edge-net sizes of BASELINE configs[2..4]."""
+import json
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from brepgen_amd import ops
+
+from brepgen_amd import _lib, ops
+
+lib = _lib.load()
 g = torch.Generator().manual_seed(0)
-def timed(fn, iters=20):
-    for _ in range(3): fn()
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): fn()
-    e1.record(); torch.cuda.synchronize()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1000 / iters
-for B, N in [(512, 60), (512, 30), (8, 1800), (2, 4000), (16, 2400)]:
-    qkv = torch.randn(B * N, 2304, generator=g).cuda().to(torch.bfloat16)
-    mask = torch.zeros(B, N, dtype=torch.bool).cuda()
-    us = timed(lambda: ops.attention(qkv, mask, B, N), iters=10)
-    print(f"attn bf16 B={B} N={N}: {us:.1f} us  {4.0 * B * 12 * N * N * 64 / us / 1e6:.1f} TFLOP/s", flush=True)
+
+
+rows = []
+for B, N, dt in [(256, 1800, torch.bfloat16), (64, 4000, torch.bfloat16), (128, 2400, torch.float16), (512, 60, torch.bfloat16), (512, 128, torch.bfloat16)]:
+    qkv = (torch.randn(B * N, 2304, generator=g) * 0.7).to(dt).cuda()
+    out = torch.empty(B * N, 768, dtype=dt, device="cuda")
+    nvalid = torch.randint(max(1, N // 8), N + 1, (B,), generator=g)
+    mask = (torch.arange(N)[None] >= nvalid[:, None]).cuda()
+    offs = torch.zeros(B + 1, dtype=torch.int32)
+    offs[1:] = torch.cumsum(nvalid, 0)
+    offs = offs.cuda()
+    code = {torch.bfloat16: _lib.BG_BF16, torch.float16: _lib.BG_F16}[dt]
+    call = lambda kp, of: _lib.check(lib.bg_attn_varlen_fwd(qkv.data_ptr(), kp, out.data_ptr(), B, N, code, of, _lib.stream()), "attn")
+    cases = {"dense": (None, None, float(B) * N * N), "ragged-mask": (mask.view(torch.uint8).data_ptr(), None, float(B) * N * N),
+             "varlen": (None, offs.data_ptr(), float((nvalid.double() ** 2).sum()))}
+    for name, (kp, of, pairs) in cases.items():
+        res = {}
+        for rnd in range(2):
+            for variant in ((1, 0) if N > 64 else (0,)):
+                lib.bg_tune_set(6, variant)
+                us = timed(lambda: call(kp, of), 5 if N > 64 else 20)
+                res.setdefault("old" if variant else "new", []).append(us)
+        lib.bg_tune_set(6, 0)
+        row = {"B": B, "N": N, "dtype": str(dt)[6:], "case": name,
+               **{k: {"us": round(min(v), 1), "tflops_executed": round(4.0 * 12 * 64 * pairs / min(v) / 1e6, 1)} for k, v in res.items()}}
+        rows.append(row)
+        print(json.dumps(row), flush=True)
