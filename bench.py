@@ -187,6 +187,58 @@ def edge_net_extra(dev, evals=2):
     return out
 
 
+def face_ldm_extra(dev, steps=20):
+    """The other pieces of the face LDM beside the headline: SurfPosNet [512,60,6] + DDPM update (no mask:
+    dense by construction) and the SurfZNet step with the PNDM update the cascade actually runs for it (sample.py:189-202)."""
+    import brepgen_amd as bga
+    torch.manual_seed(2)
+    out = {}
+    kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001, beta_end=0.02)
+    ddpm = bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw)
+    ddpm.set_timesteps(1000)
+    pndm = bga.PNDMScheduler(**kw)
+    pndm.set_timesteps(200)
+    z, pos, mask = make_inputs(B_PER_GPU, dev, 4321)
+
+    def clock(fn, n):
+        fn(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i + 1)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    with torch.no_grad():
+        net = bga.SurfPosNet(False).to(dev).eval()
+        net.compute_dtype = torch.bfloat16
+        state = {"x": pos.clone()}
+        ts, ts_dev = ddpm.timesteps[-250:], ddpm.timesteps[-250:].to(dev)
+
+        def surfpos_step(i):
+            eps = net(state["x"], ts_dev[i:i + 1], None)
+            state["x"] = ddpm.step(eps, ts[i], state["x"], noise=torch.randn_like(eps)).prev_sample
+        dt = clock(surfpos_step, steps)
+        f = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 2.38e6)
+        out["surfpos_ddpm_step"] = {"workload": "SurfPosNet eps-eval [512,60,6] + DDPM update, bf16", "ms_per_step": round(dt * 1e3, 3),
+                                    "steps_per_s": round(1 / dt, 2), "model_tflops": round(f / dt / 1e12, 1)}
+        del net
+        net = bga.SurfZNet(False).to(dev).eval()
+        net.compute_dtype = torch.bfloat16
+        net.cache_conditioning = False
+        state = {"x": z.clone()}
+        pts, pts_dev = pndm.timesteps, pndm.timesteps.to(dev)
+
+        def surfz_pndm_step(i):
+            eps = net(state["x"], pts_dev[i:i + 1], pos, mask, None)
+            state["x"] = pndm.step(eps, pts[i], state["x"]).prev_sample
+        dt = clock(surfz_pndm_step, steps)
+        out["surfz_pndm_step"] = {"workload": "SurfZNet eps-eval [512,60,48]+bbox+mask (variable-length) + PNDM update "
+                                              "(PRK warm-up then PLMS), bf16", "ms_per_step": round(dt * 1e3, 3),
+                                  "steps_per_s": round(1 / dt, 2)}
+    return out
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
     written by tools/pmc_summary.py: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2
@@ -322,6 +374,7 @@ def main():
         net.varlen, net.profile_hints = True, hints
     if world == 1 and rank == 0 and not args.no_extra:
         extra["edge_nets"] = edge_net_extra(dev)
+        extra["face_ldm"] = face_ldm_extra(dev)
 
     roofline = None
     breakdown = None

@@ -237,12 +237,23 @@ __device__ __forceinline__ void dma16_asm(const void* gsrc, void* lds_wave_base)
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
+// value of `v` in lane ^ 32, by one v_permlane32_swap (pure VALU, no LDS crossbar)
+__device__ __forceinline__ float other_half(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    // hipcc (ROCm 7.2) folds the two results of permlane32_swap(x, x) as if they were equal -- max(r0, r1) became r0 and
+    // half of every query's keys dropped out of the running maximum; an empty asm keeps the operands distinct values
+    asm volatile("" : "+v"(b));
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    // r[0] = (a.lo, b.lo), r[1] = (a.hi, b.hi): lanes < 32 find the other half's value in r[1], lanes >= 32 in r[0]
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 constexpr int AL_MAX_N = 4096;       // longest sequence the long kernel stages a mask for (ABC edge nets: 4000)
 
 template <bool F16>
 __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
                                                              void* __restrict__ out_, int B, int N, int nqb,
-                                                             const int* __restrict__ offsets) {
+                                                             const int* __restrict__ offsets, int prio) {
     using E = AElem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
 
         // ---- S^T = K Q^T for both 32-key sub-tiles ----
         f32x16 s[2];
+        if (prio) __builtin_amdgcn_s_setprio(1);                 // A/B knob (bg_tune key 7): matrix segments at priority 1
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
                 s[sub] = E::mfma(kf, qf[ks], s[sub]);
             }
         }
+        if (prio) __builtin_amdgcn_s_setprio(0);
         // register r of sub-tile sub <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
         if (tflag[t]) {
 #pragma unroll
@@ -392,10 +405,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
         float mloc = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(fmaxf(mloc, s[0][r]), s[1][r]);
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-            mloc = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-        }
+        mloc = fmaxf(mloc, other_half(mloc));                    // the query's other 32 keys live in lane ^ 32
         // deferred maximum: rescale only when some query's maximum grew by more than 3 (or at its first valid tile)
         if (!__all(mloc <= m_run + 3.0f)) {
             const float m_new = fmaxf(m_run, mloc);
@@ -440,10 +450,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
             }
     }
 
-    {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, l_run), __builtin_bit_cast(unsigned, l_run), false, false);
-        l_run = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
-    }
+    l_run += other_half(l_run);
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     const int q = q0 + (lane & 31);
     if (q < N) {
@@ -543,8 +550,8 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
         } else {
             const int nqb = (N + 127) / 128;
             const dim3 grid(nqb * BG_N_HEAD * B);
-            if (f16) hipLaunchKernelGGL((attn16_long_kernel<true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
-            else hipLaunchKernelGGL((attn16_long_kernel<false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            if (f16) hipLaunchKernelGGL((attn16_long_kernel<true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            else hipLaunchKernelGGL((attn16_long_kernel<false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
         }
         return launch_status("attn16");
     }
