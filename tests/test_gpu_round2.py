@@ -261,8 +261,9 @@ def test_compact_rows_is_exact(pc, B, n_mask, rep):
         mask[1] = True                                    # a sample with no valid token at all
     offs = torch.full((B + 1,), -1, dtype=torch.int32, device="cuda")
     src = torch.full((B * n_mask * rep,), -1, dtype=torch.int32, device="cuda")
-    _lib.check(_lib.load().bg_compact_rows(mask.cuda().view(torch.uint8).data_ptr(), B, n_mask, rep, offs.data_ptr(),
-                                          src.data_ptr(), _lib.stream()), "bg_compact_rows")
+    m_dev = mask.cuda().view(torch.uint8)                 # named: a temporary would be recycled before the launch reads it
+    _lib.check(_lib.load().bg_compact_rows(m_dev.data_ptr(), B, n_mask, rep, offs.data_ptr(), src.data_ptr(), _lib.stream()),
+               "bg_compact_rows")
     valid = (~mask).repeat_interleave(rep, dim=1)         # [B, n_mask*rep]
     counts = valid.sum(1)
     want_offs = torch.zeros(B + 1, dtype=torch.int64)
@@ -300,7 +301,8 @@ def test_attention_over_compacted_batch(pc, N, dt):
     qd = qkv.to(dt)
     out = torch.zeros(M, 768, dtype=dt, device="cuda")
     code = {BF16: _lib.BG_BF16, F32: _lib.BG_F32}[dt]
-    _lib.check(_lib.load().bg_attn_varlen_fwd(qd.cuda().data_ptr(), None, out.data_ptr(), B, N, code, offs.cuda().data_ptr(),
+    q_dev, o_dev = qd.cuda(), offs.cuda()                 # named: a temporary would be recycled before the launch reads it
+    _lib.check(_lib.load().bg_attn_varlen_fwd(q_dev.data_ptr(), None, out.data_ptr(), B, N, code, o_dev.data_ptr(),
                                              _lib.stream()), "bg_attn_varlen_fwd")
     worst = 0.0
     for b in range(B):
