@@ -250,7 +250,7 @@ __device__ __forceinline__ float other_half(float v) {
 
 constexpr int AL_MAX_N = 4096;       // longest sequence the long kernel stages a mask for (ABC edge nets: 4000)
 
-template <bool F16>
+template <bool F16, bool MASKED>      // MASKED: a key-padding mask is given (dense execution); otherwise only keys >= N are dead
 __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
                                                              void* __restrict__ out_, int B, int N, int nqb,
                                                              const int* __restrict__ offsets, int prio) {
@@ -282,41 +282,6 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
     const T* base = qkv + row_base * QKV_LD + head * 64;
     const int q0 = qb * 128 + wave * 32;
 
-    // ---- key flags of the whole sample into LDS (once), last valid key, per-tile "has a masked key" flags ----
-    const int nkt_all = (N + 63) / 64;
-    int last = 0;
-    for (int k = tid; k < nkt_all * 64; k += 256) {
-        const bool dead = k >= N || (key_pad != nullptr && key_pad[row_base + k] != 0);
-        kp[k] = dead ? 1 : 0;
-        last = dead ? last : k + 1;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    if (lane == 0) nk_sh[wave] = last;
-    __syncthreads();
-    const int n_keys = max(max(nk_sh[0], nk_sh[1]), max(nk_sh[2], nk_sh[3]));
-    const int nkt = (n_keys + 63) / 64;                  // key tiles beyond the last valid key are never visited
-    if (tid < nkt) {
-        const uint4* w = reinterpret_cast<const uint4*>(kp + tid * 64);
-        const uint4 a = w[0], b4 = w[1], c = w[2], d = w[3];
-        tflag[tid] = ((a.x | a.y | a.z | a.w | b4.x | b4.y | b4.z | b4.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) != 0u) ? 1 : 0;
-    }
-
-    // ---- Q fragments (B operand of S^T = K Q^T): lane = (query l & 31, k-chunk h) per 16-wide slice of d ----
-    V8 qf[4];
-    {
-        int qrow = q0 + (lane & 31);
-        qrow = qrow < N ? qrow : N - 1;
-        const T* qp = base + (size_t)qrow * QKV_LD;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + (ks * 2 + h) * 8);
-        // have hipcc wait for these loads HERE: a register load still pending at the loop head would make it drain the
-        // whole VMEM queue -- including the next tile's DMA -- in every iteration of the tile loop
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
-    }
-    __syncthreads();                                     // tflag visible
-
     // ---- DMA: wave w moves K pieces 2w, 2w+1 and V pieces 2w, 2w+1 of a tile (a piece = 8 keys x 128 B) ----
     const int prow = lane >> 3, pch = lane & 7;
     auto issue_tile = [&](int t, int st) {
@@ -334,6 +299,49 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
             dma16_asm(src + 2 * BG_D_MODEL + vc * 8, kbase + 64 * 128 + piece * 1024);
         }
     };
+    // the first tile's fetch goes out before anything else, so its latency overlaps the rest of the prologue (key 0 is
+    // fetched even if the whole sample turns out to be masked: harmless)
+    issue_tile(0, 0);
+
+    // ---- masked execution: key flags of the whole sample into LDS (once), last valid key, per-tile flags ----
+    int n_keys = N;
+    if (MASKED) {
+        const int nkt_all = (N + 63) / 64;
+        int last = 0;
+        for (int k = tid; k < nkt_all * 64; k += 256) {
+            const bool dead = k >= N || key_pad[row_base + k] != 0;
+            kp[k] = dead ? 1 : 0;
+            last = dead ? last : k + 1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+        if (lane == 0) nk_sh[wave] = last;
+        __syncthreads();
+        n_keys = max(max(nk_sh[0], nk_sh[1]), max(nk_sh[2], nk_sh[3]));
+    }
+    const int nkt = (n_keys + 63) / 64;                  // key tiles beyond the last valid key are never visited
+    if (MASKED) {
+        if (tid < nkt) {
+            const uint4* w = reinterpret_cast<const uint4*>(kp + tid * 64);
+            const uint4 a = w[0], b4 = w[1], c = w[2], d = w[3];
+            tflag[tid] = ((a.x | a.y | a.z | a.w | b4.x | b4.y | b4.z | b4.w | c.x | c.y | c.z | c.w | d.x | d.y | d.z | d.w) != 0u) ? 1 : 0;
+        }
+        __syncthreads();                                 // tflag visible
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane = (query l & 31, k-chunk h) per 16-wide slice of d ----
+    V8 qf[4];
+    {
+        int qrow = q0 + (lane & 31);
+        qrow = qrow < N ? qrow : N - 1;
+        const T* qp = base + (size_t)qrow * QKV_LD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qp + (ks * 2 + h) * 8);
+        // have hipcc wait for these loads HERE: a register load still pending at the loop head would make it drain the
+        // whole VMEM queue -- including the next tile's DMA -- in every iteration of the tile loop
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
+    }
 
     // K fragment offsets (A operand of S^T): key row l & 31 of each 32-key sub-tile, 16-byte chunk ks*2+h, swizzled
     int k_off[2], k_sw[2];
@@ -367,7 +375,6 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
     float m_run = -INFINITY, l_run = 0.f;
     constexpr float LOG2E = 1.4426950408889634f;
 
-    if (nkt > 0) issue_tile(0, 0);
     for (int t = 0; t < nkt; ++t) {
         const int st = t & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my pieces of tile t (issued one tile ago) landed
@@ -391,15 +398,25 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
         }
         if (prio) __builtin_amdgcn_s_setprio(0);
         // register r of sub-tile sub <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
-        if (tflag[t]) {
+        if (MASKED) {
+            if (tflag[t]) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const unsigned w = *reinterpret_cast<const unsigned*>(kp + t * 64 + sub * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            s[sub][4 * g4 + e] = ((w >> (8 * e)) & 0xffu) ? -INFINITY : s[sub][4 * g4 + e];
+                    }
+            }
+        } else if ((t + 1) * 64 > N) {                            // only the last tile of an unmasked sequence has dead keys
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const unsigned w = *reinterpret_cast<const unsigned*>(kp + t * 64 + sub * 32 + 8 * g4 + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        s[sub][4 * g4 + e] = ((w >> (8 * e)) & 0xffu) ? -INFINITY : s[sub][4 * g4 + e];
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    s[sub][r] = key >= N ? -INFINITY : s[sub][r];
                 }
         }
         float mloc = fmaxf(s[0][0], s[1][0]);
@@ -450,6 +467,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
             }
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may outlive the workgroup (nkt == 0: tile 0's fetch)
     l_run += other_half(l_run);
     const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     const int q = q0 + (lane & 31);
@@ -550,8 +568,11 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
         } else {
             const int nqb = (N + 127) / 128;
             const dim3 grid(nqb * BG_N_HEAD * B);
-            if (f16) hipLaunchKernelGGL((attn16_long_kernel<true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
-            else hipLaunchKernelGGL((attn16_long_kernel<false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            const bool masked = key_pad != nullptr && offsets == nullptr;
+            if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            else if (masked) hipLaunchKernelGGL((attn16_long_kernel<false, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            else hipLaunchKernelGGL((attn16_long_kernel<false, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
         }
         return launch_status("attn16");
     }

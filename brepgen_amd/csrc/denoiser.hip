@@ -216,10 +216,16 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // ---- token embeddings -> X [M,768] fp32 ----------------------------------------------------------------
     // step-invariant part (per face): SurfZ: p_embed(surfPos); Edge nets: surfp_embed(surfPos)+surfz_embed(surfZ)
     float* fcond = nullptr;
+    // SurfZNet, variable-length, no conditioning cache: p_embed(surfPos) is computed on the compact rows (the cache, when
+    // the caller provides one, stays in the padded per-face layout so that it does not depend on the mask)
+    const bool fcond_compact = varlen && net == BG_SURFZ && in->cond_cache == nullptr;
     if (net != BG_SURFPOS) {
         fcond = in->cond_cache ? in->cond_cache : reinterpret_cast<float*>(c.ws + c.p.off_f);
         if (!(in->cond_cache && in->cond_cache_valid)) {
-            if (net == BG_SURFZ) {
+            if (net == BG_SURFZ && fcond_compact) {
+                // faces == tokens: without a cache to fill, only the valid faces need their conditioning embed
+                if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1, false, true, true))) return rc;
+            } else if (net == BG_SURFZ) {
                 if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
             } else {
                 if ((rc = embed_mlp(c, w->embed[0], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
@@ -235,7 +241,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         //  fcond [B*S] -- kept in the padded layout, so the conditioning cache is unaffected -- are looked up through the
         //  row map: sample = token / N, face = token / E)
         case BG_SURFZ:     // tokens = z_embed(x) + p_embed(surfPos) + c
-            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1, true, true, true, true, true);
+            rc = embed_mlp(c, w->embed[0], in->x, 48, M, c.X, 768, cvec, 768, N, fcond, 768, 1, true, true, true, true, !fcond_compact);
             break;
         case BG_EDGEPOS:   // tokens = edgep_embed(x) + surf[m/E] + c
             rc = embed_mlp(c, w->embed[2], in->x, 6, M, c.X, 768, cvec, 768, N, fcond, 768, E, true, true, true, true, true);

@@ -206,6 +206,9 @@ def test_varlen_equals_dense_on_valid_tokens_and_zero_elsewhere(pc, net, B, S, E
         dense = m(*dargs)
         m.varlen = True
         vl = m(*dargs)
+        m.cache_conditioning = False                      # SurfZNet then embeds the conditioning on the compact rows too
+        vl_nc = m(*dargs)
+    assert torch.equal(vl, vl_nc)                         # same GEMM rows either way: bit-identical
     assert torch.isfinite(vl).all()
     assert float(vl[~valid].abs().max()) == 0.0 if bool((~valid).any()) else True     # padded positions: exactly 0
     d = float((vl - dense)[valid].abs().max())
