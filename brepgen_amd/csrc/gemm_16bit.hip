@@ -460,6 +460,19 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         // (P_SPLIT works on 16-row x 64-column slabs, slab t = i * 2 + half, 8 columns per lane: res[buf][2 * it],
         //  res[buf][2 * it + 1] hold either the (hi, lo) octets of the split residual or 8 fp32 addend values)
         float4 res[2][4];
+        // compacted batches (SPLIT only; the launcher sends every other mapped GEMM to the generic kernel): the broadcast
+        // addends are indexed by the row's position in the PADDED token layout.  The 8 indices a lane needs (slab t,
+        // half it -> row rbase + 16 t + 8 it + lane / 8) are requested at the START of the tile, a whole K loop ahead of
+        // the residual prefetch that depends on them.
+        int ridx[8];
+        if (SPLIT && g.row_map != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                int grow = rbase + k * 8 + (lane >> 3);
+                grow = grow < Mv ? grow : Mv - 1;
+                ridx[k] = g.row_map[grow];
+            }
+        }
         auto load_res = [&](int t, int buf) {
             if (SPLIT) {
 #pragma unroll
@@ -469,7 +482,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     // two 16-byte loads either way (hi / lo octets, or 8 fp32 addends): select the ADDRESSES, so the
                     // loads themselves stay unconditional and in flight together
                     const size_t o = (size_t)grow * g.ld_res + cbase + (lane & 7) * 8;
-                    const float* ap = g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
+                    const int arow = (g.row_map != nullptr && g.map_add) ? ridx[t * 2 + it] : grow;
+                    const float* ap = g.add + (size_t)(arow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
                     const void* p0 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_hi) + o) : (const void*)ap;
                     const void* p1 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_lo) + o) : (const void*)(ap + 4);
                     res[buf][2 * it] = *reinterpret_cast<const float4*>(p0);
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                         }
                     }
                     if (g.add2) {
-                        const int crow = row_ok ? grow : Mv - 1;
+                        const int crow = (g.row_map != nullptr && g.map_add2) ? ridx[t * 2 + it] : (row_ok ? grow : Mv - 1);
                         const float* ap = g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol;
                         const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
                         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
@@ -760,7 +774,8 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     }
     const int nt = m128 * n128;
     const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
-                               (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64 && g.row_map == nullptr;
+                               (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64 &&
+                               (g.row_map == nullptr || (g.out_lo != nullptr && !g.map_out));   // mapped addends: SPLIT epilogue only
     // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
     //  persistent and the generic kernel implement them, with bit-identical arithmetic)
     const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines

@@ -3,7 +3,8 @@
 The CPU oracle cannot finish configs[1..4] in seconds -- but it is plain torch, so it runs unchanged on the GPU box's
 own device in fp32 (torch-ROCm fp32 matmul is true fp32 on gfx950: there is no TF32).  For each configuration:
 
-  * the HIP path runs the FULL batch of the configuration in its 16-bit mode (what bench.py / the cascade execute);
+  * the HIP path runs the FULL batch of the configuration in its 16-bit mode with variable-length execution -- what
+    bench.py / the cascade execute (the dense path is compared position by position in test_gpu_parity.py / _round2.py);
   * `oracle.denoisers.FORWARD[...]` (fp32, on cuda) evaluates a slice of >= 8 samples of that batch -- every op of the path
     is per-sample, and `test_gpu_fullsize.py` checks bitwise that a batch row equals the same sample run alone;
   * the HIP fp32 mode runs that slice as well and must agree with the fp32 oracle to fp32 round-off;
@@ -77,7 +78,7 @@ def test_full_size_against_fp32_oracle_and_torch_autocast(pc, cfg):
     from oracle import denoisers as orc
     from oracle import ref_formulation as rf
     net, B, S, E, dt16, cf, n_chk = CONFIGS[cfg]
-    m, sd = pc.build_net(net, 21, cf, dt16)
+    m, sd = pc.build_net(net, 21, cf, dt16, varlen=True)              # the product default: variable-length execution
     args = pc.synth_inputs(net, B, S, E, cf)
     dargs = [a.cuda() if torch.is_tensor(a) else a for a in args]
     # the checked samples: spread over the batch; with CFG half of them from the unconditional half
