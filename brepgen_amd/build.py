@@ -27,7 +27,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    files = sorted(os.listdir(CSRC)) + ["../../include/brepgen_hip.h"]
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + ["../../include/brepgen_hip.h"]   # sources only
     for f in files:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())

@@ -786,7 +786,10 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g);
     } else {
-        const int grid = nt < 512 ? (nt & ~7) : 512;              // 2 resident workgroups per CU x 256 CUs, multiple of 8
+        // 2 resident workgroups per CU x 256 CUs, multiple of 8.  (bg_tune key 3 caps it -- 256 = one workgroup per CU, so
+        // that the GEMM of a second, independent stream can be co-resident: tools/dual_stream_probe.py)
+        const int cap = (g_tune[3] >= 8 && g_tune[3] <= 512) ? (g_tune[3] & ~7) : 512;
+        const int grid = nt < cap ? (nt & ~7) : cap;
         // column groups per launch (bg_tune_set key 4).  Measured on the QKV shape (W = 3.5 MB vs a 4 MB L2 per XCD):
         // ng = 2 is not faster than ng = 1 once the clocks are warm, so 1 is shipped.
         int ng = g_tune[4] > 0 ? g_tune[4] : 1;
