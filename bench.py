@@ -175,8 +175,10 @@ def edge_net_extra(dev, evals=2):
                 row[mode] = {"ms_per_eval": round(dt * 1e3, 2), "executed_tflops": round(fl / dt / 1e12, 1),
                              "frac_of_mfma_peak": round(fl / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)}
             net.varlen = True
+            net.n_split = 1                               # per-kernel numbers: launches serialised
             with _lib.profile() as prof:
                 net(*args)
+            net.n_split = "auto"
             row["kernels_varlen"] = {r["kernel"]: {"launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                                                    "tflops": round(r["flops"] / r["total_ms"] / 1e9, 1) if r["flops"] else None,
                                                    "frac_of_mfma_peak": round(r["flops"] / r["total_ms"] / 1e9 / MFMA_PEAK_TFLOPS, 4) if r["flops"] else None}
@@ -261,6 +263,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the measurements reported beside the headline")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + JSON only, on CPU (no compute)")
     ap.add_argument("--dense", action="store_true", help="run every padded position like the reference (no compaction)")
+    ap.add_argument("--split", type=int, default=0, help="sample groups run concurrently on forked streams (0 = the "
+                                                         "module's default: 2 at this batch size; 1 = off)")
     args = ap.parse_args()
 
     ap_world = os.environ.get("WORLD_SIZE")
@@ -318,6 +322,9 @@ def main():
     net.compute_dtype = torch.bfloat16
     net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
     net.varlen = not args.dense        # variable-length execution: only the valid faces (U{8..60} of 60) run through the net
+    if args.split:
+        net.n_split = args.split       # default "auto": two groups of 256 samples on two streams inside the one C call
+    n_split = 2 if net.n_split == "auto" else int(net.n_split)
     z, pos, mask = make_inputs(B_PER_GPU, dev, 1234 + rank)
     nvalid = make_inputs.nvalid.double()
     if net.varlen:                     # the opt-in profiler books EXECUTED rows / attention pairs (host-side knowledge)
@@ -358,6 +365,19 @@ def main():
     finite = bool(torch.isfinite(out["surfZ"]).all())
 
     extra = {}
+    if n_split > 1 and not args.no_extra:
+        # the same K steps with the launches of a step serialised on one stream (n_split = 1)
+        keep = net.n_split
+        net.n_split = 1
+        run_steps(2, x, 0)
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps, x, args.warmup)
+        barrier()
+        d_el = time.perf_counter() - t1
+        extra["single_stream_execution"] = {"ms_per_step": round(1e3 * d_el / args.steps, 4),
+                                            "steps_per_s_per_gpu": round(args.steps / d_el, 3)}
+        net.n_split = keep
     if net.varlen and not args.no_extra:
         # the same K steps with dense execution (every padded position computed, as the reference does) -- reported
         # beside the headline, never part of `value`
@@ -379,9 +399,14 @@ def main():
     roofline = None
     breakdown = None
     if not args.no_roofline:
-        # second pass of the same K steps with a hipEvent pair around every kernel launch (on the launch stream)
+        # second pass of the same K steps with a hipEvent pair around every kernel launch (on the launch stream).  The
+        # launches are serialised for it (n_split = 1): with two sample groups in flight every launch shares the CUs with
+        # a launch of the other group, and its duration then says nothing about the kernel.
+        keep = net.n_split
+        net.n_split = 1
         with _lib.profile() as prof:
             run_steps(args.steps, x, args.warmup)
+        net.n_split = keep
         rows = {r["kernel"]: r for r in prof.rows}
         breakdown = {k: {"launches": r["launches"], "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                          "total_ms_per_step": round(r["total_ms"] / args.steps, 4),
@@ -393,7 +418,8 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
                     "launches_per_step": dom["launches"] // args.steps,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
-                    "flops_per_launch": dom["flops"] / dom["launches"]}
+                    "flops_per_launch": dom["flops"] / dom["launches"], "flops": "executed (valid rows only)" if net.varlen else "algorithmic",
+                    "measured_with": "launches serialised (n_split = 1); the timed region runs n_split = %d" % n_split}
 
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
@@ -414,11 +440,12 @@ def main():
                        "sample_steps_per_s": round(steps_per_s * B_PER_GPU, 1),
                        "algorithmic_tflop_per_step": round(f_step / 1e12, 3),
                        "executed_tflop_per_step": round(f_exec / 1e12, 3),
-                       "varlen": bool(net.varlen), "valid_faces_per_sample_mean": round(float(nvalid.mean()), 2),
+                       "varlen": bool(net.varlen), "n_split": n_split, "valid_faces_per_sample_mean": round(float(nvalid.mean()), 2),
                        "model_tflops_per_gpu": round(f_step * args.steps / elapsed / 1e12, 1),
                        "executed_tflops_per_gpu": round(f_exec * args.steps / elapsed / 1e12, 1),
                        "finite": finite, "parallelism": f"batch-sharded x{world}, 1 all_gather of latents",
-                       "formulation": "variable-length execution (valid faces compacted on the device; eps = 0 at padded "
+                       "formulation": "two sample groups pipelined on forked streams inside the one C call; "
+                                      "variable-length execution (valid faces compacted on the device; eps = 0 at padded "
                                       "positions, valid positions as the dense path), norm1/norm2 folded into the QKV/FFN1 "
                                       "GEMM epilogues, residual stream as (hi, lo) 16-bit planes, fused input embeds; "
                                       "conditioning cache off (every embed recomputed)"},

@@ -5,6 +5,7 @@
 #include "bg_common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 
 namespace bg {
 
@@ -370,11 +371,109 @@ extern "C" int bg_tune_set(int key, int value) {
 extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
 extern "C" const char* bg_last_error(void) { return bg::g_err; }
 
+namespace bg {
+constexpr int MAX_SPLIT = 4;
+// contiguous sample groups of an n-way split (sizes differ by at most one)
+static inline void split_range(int B, int n, int k, int& lo, int& hi) {
+    const int base = B / n, rem = B % n;
+    lo = k * base + (k < rem ? k : rem);
+    hi = lo + base + (k < rem ? 1 : 0);
+}
+static size_t plan_total_split(int net, int B, int S, int E, int dtype, int n) {
+    size_t t = 0;
+    for (int k = 0; k < n; ++k) {
+        int lo, hi;
+        split_range(B, n, k, lo, hi);
+        if (hi > lo) t += align_up(plan(net, hi - lo, S, E, dtype).total);
+    }
+    return t;
+}
+// helper streams + fork / join events of the split mode: created once, used under a mutex (enqueue only: microseconds)
+struct SplitState {
+    hipStream_t aux[MAX_SPLIT - 1];
+    hipEvent_t fork, join[MAX_SPLIT - 1];
+    bool ok = false;
+};
+static SplitState g_split;
+static std::once_flag g_split_once;
+static std::mutex g_split_mutex;
+static void split_init() {
+    bool ok = hipEventCreateWithFlags(&g_split.fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < MAX_SPLIT - 1 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&g_split.aux[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&g_split.join[i], hipEventDisableTiming) == hipSuccess;
+    g_split.ok = ok;
+}
+}  // namespace bg
+
 extern "C" size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype) {
     if (B <= 0 || S <= 0) return 0;
     if (net < BG_EDGEPOS) E = 1;
     if (E <= 0) return 0;
-    return bg::plan(net, B, S, E, dtype).total;
+    size_t t = bg::plan(net, B, S, E, dtype).total;
+    for (int n = 2; n <= bg::MAX_SPLIT; ++n) {
+        const size_t ts = bg::plan_total_split(net, B, S, E, dtype, n);
+        t = ts > t ? ts : t;
+    }
+    return t;
+}
+
+extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
+                               void* workspace, size_t workspace_bytes, bg_stream_t stream) {
+    using namespace bg;
+    BG_REQUIRE(w && in, BG_E_ARG, "bg_denoiser_fwd: null descriptor");
+    hipStream_t s = (hipStream_t)stream;
+    const int ns = in->n_split > MAX_SPLIT ? MAX_SPLIT : in->n_split;
+    if (ns < 2 || in->B < ns) return run(w, in, eps_out, workspace, workspace_bytes, s);
+
+    // ---- n-way split over sample groups, one stream each, fork / join by events on the caller's stream ----
+    const int net = w->net;
+    BG_REQUIRE(net >= BG_SURFPOS && net <= BG_EDGEZ, BG_E_ARG, "bg_denoiser_fwd: bad net id %d", net);
+    BG_REQUIRE(in->B > 0 && in->S > 0 && eps_out && workspace, BG_E_ARG, "bg_denoiser_fwd: null pointer / empty shape");
+    const int S = in->S, E = (net >= BG_EDGEPOS) ? in->E : 1;
+    BG_REQUIRE(E > 0, BG_E_SHAPE, "bg_denoiser_fwd: empty shape");
+    BG_REQUIRE(((uintptr_t)workspace & 255) == 0, BG_E_ALIGN, "bg_denoiser_fwd: workspace must be 256-byte aligned");
+    BG_REQUIRE(workspace_bytes >= plan_total_split(net, in->B, S, E, w->dtype, ns), BG_E_WORKSPACE,
+               "bg_denoiser_fwd: workspace too small for n_split = %d", ns);
+    std::call_once(g_split_once, split_init);
+    BG_REQUIRE(g_split.ok, BG_E_ARG, "bg_denoiser_fwd: could not create the helper streams of the split mode");
+    static const int kInCols[4] = {6, 48, 6, 18};                 // channels of x per net (SurfPos, SurfZ, EdgePos, EdgeZ)
+    const size_t tok = (size_t)S * E;
+    const size_t mask_per_sample = (net == BG_EDGEZ) ? tok : (size_t)S;
+    std::lock_guard<std::mutex> lock(g_split_mutex);
+    hipError_t he = hipEventRecord(g_split.fork, s);
+    BG_REQUIRE(he == hipSuccess, (int)he, "bg_denoiser_fwd: hipEventRecord failed: %s", hipGetErrorString(he));
+    unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
+    int rc = 0;
+    for (int k = 0; k < ns; ++k) {
+        int lo, hi;
+        split_range(in->B, ns, k, lo, hi);
+        bg_denoiser_inputs sub = *in;
+        sub.B = hi - lo;
+        sub.n_split = 0;
+        sub.x = in->x + (size_t)lo * tok * kInCols[net];
+        if (in->surf_pos) sub.surf_pos = in->surf_pos + (size_t)lo * S * 6;
+        if (in->surf_z) sub.surf_z = in->surf_z + (size_t)lo * S * 48;
+        if (in->edge_pos) sub.edge_pos = in->edge_pos + (size_t)lo * tok * 6;
+        if (in->mask) sub.mask = in->mask + (size_t)lo * mask_per_sample;
+        if (in->n_timesteps == in->B) { sub.timesteps = in->timesteps + lo; sub.n_timesteps = sub.B; }
+        if (in->class_label) sub.class_label = in->class_label + lo;
+        if (in->cond_cache) sub.cond_cache = in->cond_cache + (size_t)lo * S * 768;
+        sub.rows_hint = in->rows_hint * sub.B / in->B;            // profiler accounting only: proportional share
+        sub.pairs_hint = in->pairs_hint * sub.B / in->B;
+        const size_t bytes = align_up(plan(net, sub.B, S, E, w->dtype).total);
+        hipStream_t sk = k == 0 ? s : g_split.aux[k - 1];
+        if (k > 0 && (he = hipStreamWaitEvent(sk, g_split.fork, 0)) != hipSuccess) { rc = (int)he; break; }
+        rc = run(w, &sub, eps_out + (size_t)lo * tok * w->fc_out.n_out, wsp, bytes, sk);
+        if (rc) break;
+        wsp += bytes;
+    }
+    // join every helper stream back into the caller's stream -- also after an error, so nothing is left dangling
+    for (int k = 1; k < ns; ++k) {
+        if (hipEventRecord(g_split.join[k - 1], g_split.aux[k - 1]) == hipSuccess)
+            (void)hipStreamWaitEvent(s, g_split.join[k - 1], 0);
+    }
+    return rc;
 }
 
 // ---- stand-alone pieces of the whole-net call (same code paths, caller-owned scratch) ---------------------------------
@@ -439,8 +538,3 @@ extern "C" int bg_encoder_layer_fwd(const bg_layer_weights* L, int dtype, float*
     return gemm(f2, dtype, s);
 }
 
-extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out,
-                               void* workspace, size_t workspace_bytes, bg_stream_t stream) {
-    BG_REQUIRE(w && in, BG_E_ARG, "bg_denoiser_fwd: null descriptor");
-    return bg::run(w, in, eps_out, workspace, workspace_bytes, (hipStream_t)stream);
-}

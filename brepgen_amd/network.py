@@ -99,6 +99,11 @@ class _HipDenoiser(nn.Module):
         # (sample.py:284, 307-314).  False = dense execution, every position as the reference computes it.
         self.varlen = True
         self.profile_hints = None        # (valid tokens, sum of valid^2): FLOP accounting of the opt-in profiler only
+        # Software pipelining: the batch is cut into n_split groups of samples whose forwards run concurrently on forked
+        # HIP streams inside the one C call (identical results; tile-round tails and memory-bound epilogues of one group
+        # hide under the other's K loops: -7 % per step at batch 512 x 60).  "auto": 2 groups for batches of >= 16384
+        # padded tokens, otherwise off.
+        self.n_split = "auto"
         self._packs = {}
         self._workspace = None
         self._cond = None                # conditioning-embed cache entry
@@ -249,6 +254,10 @@ class _HipDenoiser(nn.Module):
         inp.cond_cache, inp.cond_cache_valid = None, 0
         inp.varlen = int(bool(self.varlen) and mk is not None and self.NET != BG_SURFPOS)
         inp.rows_hint, inp.pairs_hint = (self.profile_hints if (self.profile_hints and inp.varlen) else (0.0, 0.0))
+        ns = self.n_split
+        if ns == "auto":
+            ns = 2 if (B >= 2 and B * S * E >= 16384) else 1
+        inp.n_split = int(ns)
         # (never while a HIP graph is being captured: the flag would be baked into the graph, and a replay after the
         #  caller refreshed the static conditioning buffers through raw pointers would use stale embeds)
         use_cache = (self.cache_conditioning and surf_pos is not None and not self.training

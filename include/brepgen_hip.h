@@ -190,9 +190,17 @@ typedef struct {
     /* expected number of valid tokens / sum over samples of valid^2, ONLY for the opt-in profiler's FLOP accounting
      * (bg_profile_*); 0 = unknown (the profiler then books the padded sizes) */
     double rows_hint, pairs_hint;
+    /* Software pipelining over independent sub-batches: n_split in 2..4 cuts the batch into that many contiguous
+     * groups of samples and runs their forwards concurrently -- the first on `stream`, the others on helper streams
+     * forked from it and joined back into it by events before the call returns (HIP-graph capturable).  Every op of the
+     * path is per-sample and every kernel bit-stable across batch sizes, so the result is identical; what it buys is
+     * occupancy: the tile-round tails and the memory-bound epilogues of one group hide under the K loops of another.
+     * 0 / 1 = off.  The helper streams and events are created lazily, once per process. */
+    int n_split;
+    int _pad2;
 } bg_denoiser_inputs;
 
-/* bytes of scratch bg_denoiser_fwd needs for these shapes */
+/* bytes of scratch bg_denoiser_fwd needs for these shapes (sized so that any n_split <= 4 fits) */
 size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype);
 
 /* {SurfPosNet,SurfZNet,EdgePosNet,EdgeZNet}.forward -- network.py:1107-1126,1176-1200,1257-1286,

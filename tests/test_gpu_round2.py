@@ -313,3 +313,37 @@ def test_attention_over_compacted_batch(pc, N, dt):
         want = pc._attn_ref(qd[lo:hi], None, 1, hi - lo)
         worst = max(worst, float((out[lo:hi].float().cpu().double() - want).abs().max()))
     assert worst < (3e-2 if dt == BF16 else 1e-5), worst
+
+
+# ---- software pipelining over sample groups (n_split) --------------------------------------------------------------------
+@pytest.mark.parametrize("net,B,S,E,cf,dt,ns", [("SurfZNet", 512, 60, 1, False, BF16, 2), ("SurfZNet", 7, 60, 1, True, F32, 3),
+                                                ("EdgeZNet", 9, 7, 30, False, BF16, 4), ("EdgePosNet", 5, 8, 20, True, F16, 2),
+                                                ("SurfPosNet", 6, 30, 1, False, BF16, 4)])
+@pytest.mark.parametrize("varlen", [True, False])
+def test_split_streams_give_identical_results(pc, net, B, S, E, cf, dt, ns, varlen):
+    m, _ = pc.build_net(net, 44, cf, dt, varlen=varlen)
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs(net, B, S, E, cf)]
+    with torch.no_grad():
+        m.n_split = 1
+        one = m(*args)
+        m.n_split = ns
+        many = m(*args)
+        torch.cuda.synchronize()
+    assert torch.equal(one, many)                         # per-sample kernels, bit-stable across batch sizes
+
+
+def test_split_streams_under_graph_capture(pc):
+    m, _ = pc.build_net("SurfZNet", 6, False, BF16, varlen=True)
+    m.n_split = 2
+    a = [x.cuda() if torch.is_tensor(x) else x for x in pc.synth_inputs("SurfZNet", 8, 30, 1, False)]
+    z, t, pos, mask = a[0].clone(), a[1].cuda(), a[2].clone(), a[3]
+    with torch.no_grad():
+        want = m(z, t, pos, mask, None)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = m(z, t, pos, mask, None)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
