@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
         if (t + 1 < nkt) issue_tile(t + 1, st ^ 1);
         const unsigned char* kt_ = lds + st * STAGE;
         const unsigned char* vt_ = kt_ + 64 * 128;
+        if (q0 >= N) continue;        // a wave without a valid query (last, partly filled query block) only helps move the tiles
 
         // ---- S^T = K Q^T for both 32-key sub-tiles ----
         f32x16 s[2];

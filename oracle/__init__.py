@@ -20,9 +20,12 @@ Pinning status
   schedules: DDPM posterior of Ho et al. eq. 6-7/15, PNDM transfer / pseudo-RK / PLMS of Liu et al. eq. 11-13
   (``tests/test_oracle_pins.py``), plus the known-answer constants of SURVEY.md App. B.4.  ``tests/golden/pin_diffusers.py``
   diffs it against upstream the moment diffusers is importable.
-* ``oracle.vae`` -- PARITY UNPINNED for the same reason (the decoder / encoder blocks are diffusers code); restated from
-  the published 0.27 blocks, anchored on the reference's wiring (``network.py:30-299``) and on the parameter counts
-  SURVEY.md App. C records (asserted in ``tests/test_oracle_vae.py``).
+* ``oracle.vae`` -- the diffusers VAE blocks, restated from the published 0.27 code and anchored on the reference's wiring
+  (``network.py:30-299``) and the parameter counts of SURVEY.md App. C.  The 2-D (surface) decoder and encoder are PINNED to
+  an independent third-party implementation of the same published latent-diffusion auto-encoder that ships in this image:
+  Hugging Face ``transformers``' ``JanusVQVAEDecoder`` / ``JanusVQVAEEncoder`` with BrepGen's hyper-parameters
+  (``tests/test_oracle_vae_pin.py``, fp32 round-off).  The 1-D (edge) VAE uses diffusers' dance-diffusion blocks, for which
+  no second implementation is available offline: PARITY UNPINNED against diffusers itself.
 * ``oracle.joint_opt`` -- the Chamfer offset fit of ``utils.py:746-772``: loss semantics PARITY UNPINNED (``chamferdist``,
   unversioned third-party CUDA package), optimiser + gradient PINNED against ``torch.optim.AdamW`` + autograd
   (``tests/test_oracle_joint_opt.py``).

@@ -1,6 +1,8 @@
 """CPU restatement of the two VAE *decoders* BrepGen samples with (sample.py:72-99, 289-294).
 
-TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  *** PARITY UNPINNED ***: the decoder blocks live in the
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Pinning: the 2-D (surface) encoder / decoder restatement is PINNED to an
+independent implementation of the same published network (``transformers``' Janus VQ-VAE encoder / decoder,
+``tests/test_oracle_vae_pin.py``); the 1-D (edge) blocks are *** PARITY UNPINNED ***: the decoder blocks live in the
 third-party ``diffusers==0.27`` package (``network.py:12-13`` imports ``Decoder``, ``ResConvBlock``,
 ``SelfAttention1d``, ``Upsample1d`` from it), which is neither vendored under /root/reference nor installable
 offline.  The repo-side wiring that IS in the reference is followed line by line:
