@@ -98,8 +98,6 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                   // previous tile fully consumed
         // ---- stage K (LDS-DMA, swizzled source) ----
-        // (8-key pieces that lie entirely past the sequence -- most of a short compacted sample's tile -- are not
-        //  fetched: their keys are masked, zeros keep the masked products finite)
 #pragma unroll
         for (int j = 0; j < KPI; ++j) {
             const int q = qt * KPI + j;
@@ -107,12 +105,9 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
             const int c = (lane & 7) ^ ((row >> 1) & 7);
             int key = kt * 64 + row;
             key = key < N ? key : N - 1;
-            if (kt * 64 + q * 8 < N)                       // wave-uniform
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(base + (size_t)key * QKV_LD + BG_D_MODEL + c * 8),
-                    (__attribute__((address_space(3))) void*)(ktile + q * 1024), 16, 0, 0);
-            else
-                *reinterpret_cast<uint4*>(ktile + q * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(base + (size_t)key * QKV_LD + BG_D_MODEL + c * 8),
+                (__attribute__((address_space(3))) void*)(ktile + q * 1024), 16, 0, 0);
         }
         // ---- stage V transposed ----
 #pragma unroll
@@ -121,11 +116,7 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
             const int row = idx >> 3, dc = idx & 7;
             int key = kt * 64 + row;
             key = key < N ? key : N - 1;
-            V8 v;
-            if (kt * 64 + (qt * KPI + j) * 8 < N) v = *reinterpret_cast<const V8*>(base + (size_t)key * QKV_LD + 2 * BG_D_MODEL + dc * 8);
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
+            const V8 v = *reinterpret_cast<const V8*>(base + (size_t)key * QKV_LD + 2 * BG_D_MODEL + dc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) vt[(dc * 8 + e) * VS + row] = v[e];
         }

@@ -58,8 +58,12 @@ def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, 
     return dict(surfPos=surfPos, surfMask=surfMask, surfZ=surfZ, edgePos=edgePos, edgeM=edgeM, edgeZV=edgeZV)
 
 
+@pytest.mark.parametrize("varlen", [False, True])
 @pytest.mark.parametrize("use_cf", [False, True])
-def test_cascade_matches_oracle_cascade(use_cf):
+def test_cascade_matches_oracle_cascade(use_cf, varlen):
+    """varlen=False: dense execution, every position of every latent compared (the reference computes padded positions
+    too); varlen=True (the product default): only valid tokens run through the nets -- masks must still be identical and
+    the latents are compared where the reference's pipeline reads them (valid faces / edges; sample.py:284, 307-314)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import brepgen_amd as bga
@@ -71,6 +75,7 @@ def test_cascade_matches_oracle_cascade(use_cf):
     for n, sd in zip(names, sds):
         m = getattr(bga, n)(use_cf)
         m.load_state_dict(sd, strict=True)
+        m.varlen = varlen
         nets.append(m.cuda().eval())
     B, S, E = 2, 4, 3
     n_pos, n_ddpm, n_z = 14, 6, 14          # 12 PRK + 2 PLMS evaluations, 6 ancestral steps (the last has t = 0)
@@ -85,9 +90,13 @@ def test_cascade_matches_oracle_cascade(use_cf):
     assert set(got) == set(want)
     for k in ("surfMask", "edgeM"):
         assert torch.equal(got[k].cpu(), want[k]), k
+    valid_face = ~want["surfMask"]
     for k in ("surfPos", "surfZ", "edgePos", "edgeZV"):
         assert got[k].shape == want[k].shape, k
-        d = float((got[k].cpu() - want[k]).abs().max())
+        diff = (got[k].cpu() - want[k]).abs()
+        if varlen and k in ("surfZ", "edgePos"):
+            diff = diff[valid_face]                       # padded faces: never read downstream, not computed here
+        d = float(diff.max())
         assert np.isfinite(d) and d < 5e-4, (k, d)     # fp32 path: per-step 1e-5 compounded over ~50 steps
 
 
