@@ -57,6 +57,15 @@ class GemmDesc(C.Structure):          # bg_gemm_desc
                 ("stats_out", fp), ("stats_in", fp), ("colsum", fp), ("ln_eps", C.c_float)]
 
 
+class ConvDesc(C.Structure):          # bg_conv_desc
+    _fields_ = [("x", vp), ("S", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("up", C.c_int),
+                ("w", vp), ("bias", fp), ("N", C.c_int),
+                ("out", fp), ("ldc", C.c_int),
+                ("add", fp), ("ld_add", C.c_int),
+                ("dtype", C.c_int), ("zero_page", vp)]
+
+
 class ProfileRow(C.Structure):
     _fields_ = [("kernel", C.c_char_p), ("launches", C.c_int), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -70,6 +79,7 @@ _SIGNATURES = {
     "bg_gemm_bias_act_fwd": (C.c_int, [vp, C.c_int, vp, fp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, vp]),
     "bg_gemm_ex_fwd": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "bg_conv_gemm_fwd": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 enum { P_PLAIN16 = 0, P_FOLD16 = 1, P_GENERAL = 2, P_SPLIT = 3 };
 constexpr int FOLD_PARTS = 12;      // the persistent kernel's LayerNorm fold is compiled for K = 768 (LN width of the denoisers)
 
-template <bool F16, int MODE, bool INSTR>
+template <bool F16, int MODE, bool INSTR, bool CONV = false>      // CONV: the A operand is gathered from a conv window (implicit GEMM)
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     using E = Elem<F16>;
@@ -396,20 +396,47 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     }
     const T* a_src[A_INSTR];
     const T* b_src[B_INSTR];
+    // implicit-GEMM convolution: output pixel (sample base, oy, ox) of each DMA row; a_src then points at channel 0 of the
+    // CURRENT tap's source pixel (or at the zero page for a padded tap) and is re-derived whenever the K loop crosses a tap
+    int cv_base[CONV ? A_INSTR : 1], cv_oy[CONV ? A_INSTR : 1], cv_ox[CONV ? A_INSTR : 1];
+    auto set_tap = [&](int tap) {
+        const int ky = tap / g.cv_kw, kx = tap - ky * g.cv_kw;
+#pragma unroll
+        for (int j = 0; j < (CONV ? A_INSTR : 0); ++j) {
+            const int iy = cv_oy[j] + ky - (g.cv_kh >> 1), ix = cv_ox[j] + kx - (g.cv_kw >> 1);
+            const bool ok = (unsigned)iy < (unsigned)(g.cv_H << g.cv_up) && (unsigned)ix < (unsigned)(g.cv_W << g.cv_up);
+            const T* pix = A + ((size_t)(cv_base[j] + (iy >> g.cv_up) * g.cv_W + (ix >> g.cv_up))) * g.cv_C;
+            a_src[j] = (ok ? pix : reinterpret_cast<const T*>(g.cv_zero)) + a_chunk[j];
+        }
+    };
     auto set_src = [&](int m0, int n0) {
 #pragma unroll
         for (int j = 0; j < A_INSTR; ++j) {
             int grow = m0 + a_row[j];
             grow = grow < Mv ? grow : Mv - 1;
-            a_src[j] = A + (size_t)grow * g.lda + a_chunk[j];
+            if (CONV) {
+                cv_ox[CONV ? j : 0] = grow & ((1 << g.cv_wo_log2) - 1);
+                const int t = grow >> g.cv_wo_log2;
+                cv_oy[CONV ? j : 0] = t & ((1 << g.cv_ho_log2) - 1);
+                cv_base[CONV ? j : 0] = (t >> g.cv_ho_log2) * g.cv_H * g.cv_W;
+            } else {
+                a_src[j] = A + (size_t)grow * g.lda + a_chunk[j];
+            }
         }
+        if (CONV) set_tap(0);
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j) b_src[j] = W + (size_t)(n0 + b_row[j]) * g.K + b_chunk[j];
     };
     auto issue = [&](int slot, int k0) {
         unsigned char* sa = lds + slot * STAGE_BYTES;
+        int ka = k0;                                              // A: offset inside the row / inside the tap's C channels
+        if (CONV) {
+            const int kt_ = k0 / G_BK, spt_mask = (1 << g.cv_spt_log2) - 1;
+            if (k0 != 0 && (kt_ & spt_mask) == 0) set_tap(kt_ >> g.cv_spt_log2);   // (tap 0 was set with the tile)
+            ka = (kt_ & spt_mask) * G_BK;
+        }
 #pragma unroll
-        for (int j = 0; j < A_INSTR; ++j) lds_dma16(a_src[j] + k0, sa + (wave * A_INSTR + j) * 1024);
+        for (int j = 0; j < A_INSTR; ++j) lds_dma16(a_src[j] + ka, sa + (wave * A_INSTR + j) * 1024);
 #pragma unroll
         for (int j = 0; j < B_INSTR; ++j) lds_dma16(b_src[j] + k0, sa + BM * 128 + (wave * B_INSTR + j) * 1024);
     };
@@ -779,6 +806,10 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
     //  persistent and the generic kernel implement them, with bit-identical arithmetic)
     const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
+    if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in || variant != 0)) {
+        set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
+        return BG_E_SHAPE;
+    }
     if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
     } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
@@ -801,6 +832,8 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
             if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
             else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
+        } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
         } else if (g.out_lo) {
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
         } else if (g.stats_in) {
@@ -816,6 +849,10 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
 
 int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s) {
     if (g.M <= 0) return 0;
+    if (g.cv_C > 0 && g.N_pad % 128 != 0) {
+        set_error("gemm_16bit: the implicit-GEMM convolution needs N %% 128 == 0");
+        return BG_E_SHAPE;
+    }
     if (g.K % G_BK != 0 || g.N_pad % 64 != 0 || g.lda % 8 != 0) {
         set_error("gemm_16bit: need K %% 64 == 0, N_pad %% 64 == 0, lda %% 8 == 0 (K=%d N_pad=%d lda=%d)", g.K, g.N_pad, g.lda);
         return BG_E_SHAPE;

@@ -10,6 +10,7 @@ x2 up-sampling folded into the gather) + the MFMA GEMM with bias / residual fuse
 attention = one fused q|k|v GEMM + ``bg_small_attn`` + projection GEMM; ``Upsample1d("cubic")`` = ``bg_upsample1d_cubic``.
 The nn.Module tree below only holds parameters.  Like the denoisers, bf16 operands inside autocast, exact fp32 outside.
 """
+import ctypes
 import math
 
 import torch
@@ -147,13 +148,22 @@ class _Packed:
     __slots__ = ("w", "b", "n", "k", "dtype")
 
 
+def _pow2(v):
+    return v > 0 and (v & (v - 1)) == 0
+
+
 class _HipVAE(nn.Module):
-    IM2COL_BUDGET = 1 << 30        # bytes of im2col scratch per chunk of samples
+    IM2COL_BUDGET = 1 << 32        # bytes of im2col scratch per chunk of samples (288 GB of HBM: few, large chunks)
 
     def __init__(self):
         super().__init__()
         self.compute_dtype = None
+        # 16-bit modes: the 3x3 / k5 convolutions run as IMPLICIT GEMMs (bg_conv_gemm_fwd): GroupNorm + activation + cast in
+        # one elementwise pass, then the GEMM gathers the window itself -- the kh*kw-fold im2col matrix is never written.
+        # False = materialised im2col for every convolution (the round-1 path; also what fp32 and tiny batches use).
+        self.implicit_gemm = True
         self._packs = {}
+        self._zero = None
 
     def _apply(self, fn, *a, **k):
         self._packs = {}
@@ -215,10 +225,31 @@ class _HipVAE(nn.Module):
             py, px = pad
             Ho, Wo = (Hl + 1 - kh) // stride + 1 if kh > 1 else Hl, (Wl + 1 - kw) // stride + 1
         rows = S * Ho * Wo
-        a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
         st = self._stats(x, S, H * W, C, norm) if norm is not None else None
         g = norm.weight.detach().float().contiguous() if norm is not None else None
         b = norm.bias.detach().float().contiguous() if norm is not None else None
+        implicit = (self.implicit_gemm and pk.dtype != torch.float32 and kh * kw > 1 and stride == 1 and pad is None
+                    and C % 64 == 0 and _pow2(C // 64) and _pow2(Ho) and _pow2(Wo) and pk.n % 128 == 0
+                    and pk.w.shape[0] == pk.n and ((rows + 127) // 128) * (pk.n // 128) >= 64 and rows < 2 ** 31)
+        if implicit:
+            # normalise + activate + cast ONCE (a 1x1 "im2col"), then let the GEMM's loader walk the window
+            xn = torch.empty(S * H * W, C, device=x.device, dtype=pk.dtype)
+            check(lib.bg_im2col(ptr(x), ptr(xn), _CODE[pk.dtype], S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st), ptr(g), ptr(b),
+                                norm.num_groups if norm is not None else 1, act, None, stream()), "bg_im2col[norm+act+cast]")
+            if self._zero is None or self._zero.device != x.device:
+                self._zero = torch.zeros(256, dtype=torch.uint8, device=x.device)
+            out = torch.empty(rows, pk.n, device=x.device, dtype=torch.float32)
+            res = residual.contiguous() if residual is not None else None
+            d = _lib.ConvDesc()
+            d.x, d.S, d.H, d.W, d.C = ptr(xn), S, H, W, C
+            d.kh, d.kw, d.up = kh, kw, up
+            d.w, d.bias, d.N = ptr(pk.w), ptr(pk.b), pk.n
+            d.out, d.ldc = ptr(out), pk.n
+            d.add, d.ld_add = ptr(res), pk.n
+            d.dtype, d.zero_page = _CODE[pk.dtype], ptr(self._zero)
+            check(lib.bg_conv_gemm_fwd(ctypes.byref(d), stream()), "bg_conv_gemm_fwd")
+            return out, (S, Ho, Wo, pk.n)
+        a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
         check(lib.bg_im2col(ptr(x), ptr(a), _CODE[pk.dtype], S, H, W, C, kh, kw, up, stride, py, px, Ho, Wo,
                             ptr(st), ptr(g), ptr(b), norm.num_groups if norm is not None else 1, act, None, stream()),
               "bg_im2col")

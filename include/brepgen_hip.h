@@ -90,6 +90,27 @@ typedef struct {
 } bg_gemm_desc;
 int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
 
+/* Convolution as an IMPLICIT GEMM (the 3x3 / k5 convolutions of the VAE decoders: ResnetBlock2D.conv1/conv2, Upsample2D.conv,
+ * ResConvBlock.conv_1/conv_2 -- network.py:30-83, 188-299, 948-1040 via diffusers): the MFMA GEMM's activation loader
+ * gathers the window straight from the channels-last tensor, so the kh*kw-fold im2col matrix is never written.
+ *   x     16-bit channels-last activations [S, H, W, C] (1-D: H = 1), ALREADY normalised / activated (bg_im2col with a 1x1
+ *         window does GroupNorm + SiLU/GELU + the cast in one pass); C % 64 == 0, C / 64 a power of two
+ *   'same' convolution, stride 1, window kh x kw (odd), on the nearest-upsampled grid (H << up, W << up) = (Ho, Wo), both
+ *         powers of two; zero padding outside (padded taps read zero_page: >= 128 bytes of zeros on the device)
+ *   w     [N, kh*kw*C] 16-bit, tap-major (tap = ky*kw + kx, then channel), N % 128 == 0;  bias fp32 [N] or NULL
+ *   out   fp32 [S*Ho*Wo, N] (row stride ldc) = conv + bias (+ add: fp32 residual rows, row stride ld_add)
+ * Needs at least 64 output tiles of 128 x 128 (it runs on the persistent kernel); smaller problems: im2col + GEMM. */
+typedef struct {
+    const void* x; int S, H, W, C;
+    int kh, kw, up;
+    const void* w; const float* bias; int N;
+    float* out; int ldc;
+    const float* add; int ld_add;
+    int dtype;                 /* BG_BF16 | BG_F16: operand dtype of x and w */
+    const void* zero_page;
+} bg_conv_desc;
+int bg_conv_gemm_fwd(const bg_conv_desc* d, bg_stream_t stream);
+
 /* LayerNorm(768) of rows given as the split pair x = hi + lo (two 16-bit planes of dtype `dtype`) -> y (same dtype):
  * the denoisers' final net.norm when the residual stream is kept split. */
 int bg_layernorm_split_fwd(const void* hi, const void* lo, const float* gamma, const float* beta, void* y, int dtype,

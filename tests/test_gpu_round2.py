@@ -347,3 +347,38 @@ def test_split_streams_under_graph_capture(pc):
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+# ---- VAE convolutions as implicit GEMMs ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,n", [("surf", 20), ("edge", 96), ("surf_enc", 20), ("edge_enc", 96)])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_vae_implicit_gemm_equals_materialised_im2col(pc, kind, n, dt):
+    """bg_conv_gemm_fwd gathers the conv window in the GEMM's loader; same operand values, same k order as im2col + GEMM:
+    the two paths must agree bit for bit, and stay within the oracle tolerance of the 16-bit mode."""
+    import brepgen_amd as bga
+    from oracle import vae as ov
+    g = torch.Generator().manual_seed(7)
+    if kind == "surf":
+        sd, m, z = ov.seeded_state_dict(ov.surf_decoder_spec(), 31), bga.AutoencoderKLFastDecode(**pc.SURF_CFG), torch.randn(n, 3, 4, 4, generator=g)
+        ref = ov.surf_decode
+    elif kind == "edge":
+        sd, m, z = ov.seeded_state_dict(ov.edge_decoder_spec(), 41), bga.AutoencoderKL1DFastDecode(**pc.EDGE_CFG), torch.randn(n, 3, 4, generator=g)
+        ref = ov.edge_decode
+    elif kind == "surf_enc":
+        sd, m, z = ov.seeded_state_dict(ov.surf_encoder_spec(), 51), bga.AutoencoderKLFastEncode(**pc.SURF_CFG), torch.randn(n, 3, 32, 32, generator=g)
+        ref = ov.surf_encode
+    else:
+        sd, m, z = ov.seeded_state_dict(ov.edge_encoder_spec(), 61), bga.AutoencoderKL1DFastEncode(**pc.EDGE_CFG), torch.randn(n, 3, 32, generator=g)
+        ref = ov.edge_encode
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.compute_dtype = dt
+    with torch.no_grad():
+        m.implicit_gemm = True
+        a = m(z.cuda())
+        m.implicit_gemm = False
+        b = m(z.cuda())
+        want = ref(sd, z[:4])
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    e = float((a[:4].cpu() - want).abs().max())
+    assert e < (0.15 if dt == BF16 else 0.03) * max(1.0, float(want.abs().max())), e     # the 16-bit VAE tolerance of test_gpu_parity

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""VAE decode of BASELINE configs[2]'s output (15 360 faces + 460 800 edges, bf16): convolutions as implicit GEMMs vs the
+materialised im2col path, interleaved.  Random-init weights (the kernels do not care)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import brepgen_amd as bga
+from brepgen_amd.pipeline import EDGE_VAE_CFG, SURF_VAE_CFG
+
+torch.manual_seed(0)
+surf = bga.AutoencoderKLFastDecode(**SURF_VAE_CFG).cuda().eval()
+edge = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).cuda().eval()
+surf.compute_dtype = edge.compute_dtype = torch.bfloat16
+F_, G_ = (15360, 460800) if len(sys.argv) < 2 else (int(sys.argv[1]), int(sys.argv[2]))
+zs = torch.randn(F_, 48, device="cuda")
+ze = torch.randn(G_, 12, device="cuda")
+FLOP = F_ * 9.69e9 + G_ * 0.416e9
+out = {}
+with torch.no_grad():
+    for rnd in range(2):
+        for name, flag in (("implicit_gemm", True), ("im2col", False)):
+            surf.implicit_gemm = edge.implicit_gemm = flag
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            a = surf.decode_tokens(zs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            b = edge.decode_tokens(ze)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            out.setdefault(name, []).append({"surf_s": round(t1 - t0, 3), "edge_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
+                                             "tflops": round(FLOP / (t2 - t0) / 1e12, 1)})
+            del a, b
+print(json.dumps({"faces": F_, "edges": G_, "algorithmic_tflop": round(FLOP / 1e12, 1), **out}, indent=1))
