@@ -120,7 +120,7 @@ struct GemmArgs {
     // ---- implicit-GEMM convolution (16-bit operands, persistent kernel only; csrc/gemm_16bit.hip) ----
     // cv_C > 0: `a` is a channels-last activation tensor [S, H, W, C] (already normalised / activated), row m of the GEMM is
     // output pixel (s, oy, ox) of the 'same' stride-1 convolution on the nearest-upsampled grid (H << up, W << up), and
-    // K = kh * kw * C runs tap-major over the window; padded taps read `cv_zero` (>= 128 bytes of zeros).
+    // K = kh * kw * C runs tap-major over the window; padded taps read `cv_zero` (one pixel: 2 * C bytes of zeros).
     int cv_C = 0, cv_H = 0, cv_W = 0, cv_kh = 1, cv_kw = 1, cv_up = 0;
     int cv_wo_log2 = 0, cv_ho_log2 = 0, cv_spt_log2 = 0;      // log2 of the output grid and of C / 64 (K-steps per tap)
     const void* cv_zero = nullptr;

@@ -237,7 +237,7 @@ class _HipVAE(nn.Module):
             check(lib.bg_im2col(ptr(x), ptr(xn), _CODE[pk.dtype], S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st), ptr(g), ptr(b),
                                 norm.num_groups if norm is not None else 1, act, None, stream()), "bg_im2col[norm+act+cast]")
             if self._zero is None or self._zero.device != x.device:
-                self._zero = torch.zeros(256, dtype=torch.uint8, device=x.device)
+                self._zero = torch.zeros(4096, dtype=torch.uint8, device=x.device)     # >= 2 * C bytes: one pixel of zeros
             out = torch.empty(rows, pk.n, device=x.device, dtype=torch.float32)
             res = residual.contiguous() if residual is not None else None
             d = _lib.ConvDesc()

@@ -96,7 +96,7 @@ int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
  *   x     16-bit channels-last activations [S, H, W, C] (1-D: H = 1), ALREADY normalised / activated (bg_im2col with a 1x1
  *         window does GroupNorm + SiLU/GELU + the cast in one pass); C % 64 == 0, C / 64 a power of two
  *   'same' convolution, stride 1, window kh x kw (odd), on the nearest-upsampled grid (H << up, W << up) = (Ho, Wo), both
- *         powers of two; zero padding outside (padded taps read zero_page: >= 128 bytes of zeros on the device)
+ *         powers of two; zero padding outside (padded taps read zero_page: one pixel = 2 * C bytes of zeros on the device)
  *   w     [N, kh*kw*C] 16-bit, tap-major (tap = ky*kw + kx, then channel), N % 128 == 0;  bias fp32 [N] or NULL
  *   out   fp32 [S*Ho*Wo, N] (row stride ldc) = conv + bias (+ add: fp32 residual rows, row stride ld_add)
  * Needs at least 64 output tiles of 128 x 128 (it runs on the persistent kernel); smaller problems: im2col + GEMM. */
