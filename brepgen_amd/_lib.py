@@ -57,6 +57,9 @@ class GemmDesc(C.Structure):          # bg_gemm_desc
                 ("stats_out", fp), ("stats_in", fp), ("colsum", fp), ("ln_eps", C.c_float)]
 
 
+BG_E_ARG, BG_E_SHAPE, BG_E_WORKSPACE, BG_E_DTYPE, BG_E_ALIGN = -1, -2, -3, -4, -5      # enum bg_err
+
+
 class ConvDesc(C.Structure):          # bg_conv_desc
     _fields_ = [("x", vp), ("S", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("up", C.c_int),
@@ -64,6 +67,15 @@ class ConvDesc(C.Structure):          # bg_conv_desc
                 ("out", fp), ("ldc", C.c_int),
                 ("add", fp), ("ld_add", C.c_int),
                 ("dtype", C.c_int), ("zero_page", vp)]
+
+
+class VaeOp(C.Structure):             # bg_vae_op
+    _fields_ = [("op", C.c_int), ("src", C.c_int), ("dst", C.c_int), ("res", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("up", C.c_int), ("stride", C.c_int), ("pad_mode", C.c_int),
+                ("n_out", C.c_int), ("n_pad", C.c_int), ("w_dtype", C.c_int),
+                ("w", vp), ("bias", fp), ("gn_gamma", fp), ("gn_beta", fp), ("gn_groups", C.c_int),
+                ("gn_eps", C.c_float), ("act", C.c_int), ("heads", C.c_int), ("scale", C.c_float),
+                ("n_pad2", C.c_int), ("w2_dtype", C.c_int), ("w2", vp), ("bias2", fp)]
 
 
 class ProfileRow(C.Structure):
@@ -80,6 +92,9 @@ _SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, vp]),
     "bg_gemm_ex_fwd": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "bg_conv_gemm_fwd": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "bg_vae_workspace_bytes": (C.c_size_t, [C.POINTER(VaeOp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bg_vae_run": (C.c_int, [C.POINTER(VaeOp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, C.c_int, fp, vp, vp,
+                             C.c_size_t, vp]),
     "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),

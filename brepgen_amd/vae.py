@@ -9,6 +9,10 @@ Execution: channels-last fp32 activations; every convolution = ``bg_im2col`` (Gr
 x2 up-sampling folded into the gather) + the MFMA GEMM with bias / residual fused in its epilogue; mid-block
 attention = one fused q|k|v GEMM + ``bg_small_attn`` + projection GEMM; ``Upsample1d("cubic")`` = ``bg_upsample1d_cubic``.
 The nn.Module tree below only holds parameters.  Like the denoisers, bf16 operands inside autocast, exact fp32 outside.
+
+A pass is ONE C call: each module compiles itself (once per dtype) into a flat ``bg_vae_op`` program and ``bg_vae_run``
+enqueues every launch of it, chunking the batch against a caller-owned workspace (``executor = True``, the default).
+``executor = False`` drives the same primitives step by step from Python (the round-1 path, kept as the cross-check).
 """
 import ctypes
 import math
@@ -152,7 +156,87 @@ def _pow2(v):
     return v > 0 and (v & (v - 1)) == 0
 
 
+VOP_CONV, VOP_NORM_ACT_ADD, VOP_ATTN, VOP_UP1D, VOP_DOWN1D = 0, 1, 2, 3, 4
+VAE_OUT = 255
+
+
+class _Program:
+    """A flat bg_vae_op program under construction: steps + a free-list slot allocator (slot 0 = the input)."""
+
+    def __init__(self):
+        self.steps, self.keep, self._free, self.n_slots = [], [], [], 1
+        self.ops = None
+
+    def new(self):
+        if self._free:
+            return self._free.pop()
+        self.n_slots += 1
+        return self.n_slots - 1
+
+    def free(self, *slots):
+        self._free.extend(s for s in dict.fromkeys(slots) if s > 0 and s not in self._free)
+
+    def step(self, op, src, dst, res=-1):
+        o = _lib.VaeOp()
+        o.op, o.src, o.res = op, src, res
+        o.dst = self.new() if dst is None else dst
+        o.stride = 1
+        self.steps.append(o)
+        return o
+
+    def norm(self, o, norm, act):
+        g, b = norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous()
+        self.keep += [g, b]
+        o.gn_gamma, o.gn_beta, o.gn_groups, o.gn_eps, o.act = ptr(g), ptr(b), norm.num_groups, norm.eps, act
+
+    def conv(self, src, pk, kh, kw, up=0, norm=None, act=ACT_NONE, res=-1, stride=1, pad_mode=0, dst=None, n_out=None):
+        o = self.step(VOP_CONV, src, dst, res)
+        o.kh, o.kw, o.up, o.stride, o.pad_mode = kh, kw, up, stride, pad_mode
+        o.n_out, o.n_pad, o.w_dtype = pk.n if n_out is None else n_out, pk.w.shape[0], _CODE[pk.dtype]
+        o.w, o.bias = ptr(pk.w), ptr(pk.b)
+        if norm is not None:
+            self.norm(o, norm, act)
+        return o.dst
+
+    def attn(self, src, qkv, proj, norm, heads, scale):
+        o = self.step(VOP_ATTN, src, None)
+        o.n_pad, o.w_dtype, o.w, o.bias = qkv.w.shape[0], _CODE[qkv.dtype], ptr(qkv.w), ptr(qkv.b)
+        o.n_pad2, o.w2_dtype, o.w2, o.bias2 = proj.w.shape[0], _CODE[proj.dtype], ptr(proj.w), ptr(proj.b)
+        o.heads, o.scale = heads, scale
+        self.norm(o, norm, ACT_NONE)
+        self.free(src)
+        return o.dst
+
+    def resnet2d(self, x, P, name, r):                 # diffusers ResnetBlock2D
+        h = self.conv(x, P[name + "c1"], 3, 3, norm=r.norm1, act=ACT_SILU)
+        sc = self.conv(x, P[name + "sc"], 1, 1) if name + "sc" in P else x
+        out = self.conv(h, P[name + "c2"], 3, 3, norm=r.norm2, act=ACT_SILU, res=sc)
+        self.free(h, x, sc)
+        return out
+
+    def resconv(self, x, P, name, r):                  # diffusers ResConvBlock (see _HipVAE._resconv)
+        h1 = self.conv(x, P[name + "c1"], 1, 5)
+        h2 = self.conv(h1, P[name + "c2"], 1, 5, norm=r.group_norm_1, act=ACT_GELU)
+        self.free(h1)
+        sk = self.conv(x, P[name + "sk"], 1, 1) if name + "sk" in P else x
+        o = self.step(VOP_NORM_ACT_ADD, h2, None, sk)
+        self.norm(o, r.group_norm_2, ACT_GELU)
+        self.free(h2, x, sk)
+        return o.dst
+
+    def resample1d(self, x, op):
+        o = self.step(op, x, None)
+        self.free(x)
+        return o.dst
+
+    def finish(self):
+        assert self.steps[-1].dst == VAE_OUT and self.n_slots <= 8
+        self.ops = (_lib.VaeOp * len(self.steps))(*self.steps)
+        return self
+
+
 class _HipVAE(nn.Module):
+    WS_BUDGET = 16 << 30           # bytes of bg_vae_run workspace (activation slots + scratch) per chunk of samples
     IM2COL_BUDGET = 1 << 32        # bytes of im2col scratch per chunk of samples (288 GB of HBM: few, large chunks)
 
     def __init__(self):
@@ -162,16 +246,46 @@ class _HipVAE(nn.Module):
         # one elementwise pass, then the GEMM gathers the window itself -- the kh*kw-fold im2col matrix is never written.
         # False = materialised im2col for every convolution (the round-1 path; also what fp32 and tiny batches use).
         self.implicit_gemm = True
+        self.executor = True           # one bg_vae_run call per pass; False (or implicit_gemm False): step by step from Python
         self._packs = {}
+        self._programs = {}
         self._zero = None
 
     def _apply(self, fn, *a, **k):
-        self._packs = {}
+        self._packs, self._programs = {}, {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packs = {}
+        self._packs, self._programs = {}, {}
         return super().load_state_dict(*a, **k)
+
+    def _zero_page(self, device):
+        if self._zero is None or self._zero.device != device:
+            self._zero = torch.zeros(4096, dtype=torch.uint8, device=device)     # >= 2 * C bytes: one pixel of zeros
+        return self._zero
+
+    def _run(self, x_cl, out_shape, dt):
+        """bg_vae_run over the whole batch x_cl [n, (H,) W, C] -> [n, *out_shape]; chunks sized to WS_BUDGET."""
+        if dt not in self._programs:
+            self._programs[dt] = self._program(_Program(), self._pack(dt)).finish()
+        pg, lib = self._programs[dt], _lib.load()
+        n = x_cl.shape[0]
+        h, w, c = (1, *x_cl.shape[1:]) if x_cl.dim() == 3 else x_cl.shape[1:]
+        out = torch.empty(n, *out_shape, device=x_cl.device, dtype=torch.float32)
+        size = lambda n_, chunk: lib.bg_vae_workspace_bytes(pg.ops, len(pg.steps), pg.n_slots, h, w, c, n_, chunk)
+        ref = min(n, 4096)
+        per_sample = max(1, size(ref, ref) // ref)
+        chunk = max(1, min(n, self.WS_BUDGET // per_sample))
+        need = size(n, chunk)
+        if need == 0:
+            raise _lib.BrepgenHipError("bg_vae_workspace_bytes: malformed VAE program")
+        ws = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
+        check(lib.bg_vae_run(pg.ops, len(pg.steps), pg.n_slots, h, w, c, ptr(x_cl), n, chunk, ptr(out),
+                             ptr(self._zero_page(x_cl.device)), ptr(ws), need, stream()), "bg_vae_run")
+        return out
+
+    def _use_executor(self):
+        return self.executor and self.implicit_gemm
 
     def _dtype(self):
         if self.compute_dtype is not None:
@@ -236,8 +350,6 @@ class _HipVAE(nn.Module):
             xn = torch.empty(S * H * W, C, device=x.device, dtype=pk.dtype)
             check(lib.bg_im2col(ptr(x), ptr(xn), _CODE[pk.dtype], S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st), ptr(g), ptr(b),
                                 norm.num_groups if norm is not None else 1, act, None, stream()), "bg_im2col[norm+act+cast]")
-            if self._zero is None or self._zero.device != x.device:
-                self._zero = torch.zeros(4096, dtype=torch.uint8, device=x.device)     # >= 2 * C bytes: one pixel of zeros
             out = torch.empty(rows, pk.n, device=x.device, dtype=torch.float32)
             res = residual.contiguous() if residual is not None else None
             d = _lib.ConvDesc()
@@ -246,7 +358,7 @@ class _HipVAE(nn.Module):
             d.w, d.bias, d.N = ptr(pk.w), ptr(pk.b), pk.n
             d.out, d.ldc = ptr(out), pk.n
             d.add, d.ld_add = ptr(res), pk.n
-            d.dtype, d.zero_page = _CODE[pk.dtype], ptr(self._zero)
+            d.dtype, d.zero_page = _CODE[pk.dtype], ptr(self._zero_page(x.device))
             check(lib.bg_conv_gemm_fwd(ctypes.byref(d), stream()), "bg_conv_gemm_fwd")
             return out, (S, Ho, Wo, pk.n)
         a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
@@ -359,6 +471,24 @@ class AutoencoderKLFastDecode(_HipVAE):
         self._packs[dt] = P
         return P
 
+    def _program(self, pg, P):
+        d = self.decoder
+        x = pg.conv(0, P["pq"], 1, 1)
+        x2 = pg.conv(x, P["in"], 3, 3)
+        pg.free(x)
+        x = pg.resnet2d(x2, P, "m0", d.mid_block.resnets[0])
+        x = pg.attn(x, P["maqkv"], P["maproj"], d.mid_block.attentions[0].group_norm, 1, 1.0 / math.sqrt(self.block_out[-1]))
+        x = pg.resnet2d(x, P, "m1", d.mid_block.resnets[1])
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x = pg.resnet2d(x, P, f"u{bi}r{ri}", r)
+            if hasattr(blk, "upsamplers"):
+                x2 = pg.conv(x, P[f"u{bi}up"], 3, 3, up=1)
+                pg.free(x)
+                x = x2
+        pg.conv(x, P["out"], 3, 3, norm=d.conv_norm_out, act=ACT_SILU, dst=VAE_OUT)
+        return pg
+
     def _decode_chunk(self, z_cl, dt):
         """z_cl: channels-last fp32 [S,4,4,latent] -> [S,32,32,out]."""
         P = self._pack(dt)
@@ -389,6 +519,8 @@ class AutoencoderKLFastDecode(_HipVAE):
         dt = self._dtype()
         n = z_cl.shape[0]
         side = z_cl.shape[1] * 2 ** (len(self.block_out) - 1)
+        if self._use_executor():
+            return self._run(z_cl, (side, side, self.out_ch), dt)
         worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
@@ -441,6 +573,23 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         self._packs[dt] = P
         return P
 
+    def _program(self, pg, P):
+        d = self.decoder
+        x = pg.conv(0, P["pq"], 1, 1)
+        x2 = pg.conv(x, P["in"], 1, 3)
+        pg.free(x)
+        x = x2
+        c = self.block_out[-1]
+        for i in range(6):
+            x = pg.resconv(x, P, f"m{i}", d.mid_block.resnets[i])
+            x = pg.attn(x, P[f"a{i}qkv"], P[f"a{i}proj"], d.mid_block.attentions[i].group_norm, c // 32, 1.0 / math.sqrt(32))
+        for bi, blk in enumerate(d.up_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x = pg.resconv(x, P, f"u{bi}r{ri}", r)
+            x = pg.resample1d(x, VOP_UP1D)
+        pg.conv(x, P["out"], 1, 3, norm=d.conv_norm_out, act=ACT_SILU, dst=VAE_OUT)
+        return pg
+
     def _decode_chunk(self, z_cl, dt):
         P = self._pack(dt)
         d = self.decoder
@@ -472,6 +621,8 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         dt = self._dtype()
         n = z_cl.shape[0]
         length = z_cl.shape[1] * 2 ** len(self.block_out)
+        if self._use_executor():
+            return self._run(z_cl, (length, self.out_ch), dt)
         worst = length * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
@@ -577,6 +728,24 @@ class AutoencoderKLFastEncode(_HipVAE):
         self._packs[dt] = P
         return P
 
+    def _program(self, pg, P):
+        e = self.encoder
+        x = pg.conv(0, P["in"], 3, 3)
+        for bi, blk in enumerate(e.down_blocks):
+            for ri, r in enumerate(blk.resnets):
+                x = pg.resnet2d(x, P, f"d{bi}r{ri}", r)
+            if hasattr(blk, "downsamplers"):
+                x2 = pg.conv(x, P[f"d{bi}dn"], 3, 3, stride=2, pad_mode=1)
+                pg.free(x)
+                x = x2
+        x = pg.resnet2d(x, P, "m0", e.mid_block.resnets[0])
+        x = pg.attn(x, P["maqkv"], P["maproj"], e.mid_block.attentions[0].group_norm, 1, 1.0 / math.sqrt(self.block_out[-1]))
+        x = pg.resnet2d(x, P, "m1", e.mid_block.resnets[1])
+        x2 = pg.conv(x, P["out"], 3, 3, norm=e.conv_norm_out, act=ACT_SILU)
+        pg.free(x)
+        pg.conv(x2, P["q"], 1, 1, dst=VAE_OUT, n_out=self.latent)       # DiagonalGaussianDistribution(moments).mode() = mean
+        return pg
+
     def _encode_chunk(self, x_cl, dt):
         P, e = self._pack(dt), self.encoder
         S = x_cl.shape[0]
@@ -604,6 +773,9 @@ class AutoencoderKLFastEncode(_HipVAE):
         """Channels-last point grids [F,32,32,3] -> channels-last latent modes [F,4,4,3]."""
         dt = self._dtype()
         n, side = x_cl.shape[0], x_cl.shape[1]
+        if self._use_executor():
+            lat = side >> (len(self.block_out) - 1)
+            return self._run(x_cl, (lat, lat, self.latent), dt)
         worst = side * side * 9 * self.block_out[0] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
@@ -648,6 +820,22 @@ class AutoencoderKL1DFastEncode(_HipVAE):
         self._packs[dt] = P
         return P
 
+    def _program(self, pg, P):
+        e = self.encoder
+        x = pg.conv(0, P["in"], 1, 3)
+        for bi, blk in enumerate(e.down_blocks):
+            x = pg.resample1d(x, VOP_DOWN1D)
+            for ri, r in enumerate(blk.resnets):
+                x = pg.resconv(x, P, f"d{bi}r{ri}", r)
+        c = self.block_out[-1]
+        for i in range(6):
+            x = pg.resconv(x, P, f"m{i}", e.mid_block.resnets[i])
+            x = pg.attn(x, P[f"a{i}qkv"], P[f"a{i}proj"], e.mid_block.attentions[i].group_norm, c // 32, 1.0 / math.sqrt(32))
+        x2 = pg.conv(x, P["out"], 1, 3, norm=e.conv_norm_out, act=ACT_SILU)
+        pg.free(x)
+        pg.conv(x2, P["q"], 1, 1, dst=VAE_OUT, n_out=self.latent)
+        return pg
+
     def _encode_chunk(self, x_cl, dt):
         P, e = self._pack(dt), self.encoder
         S, L = x_cl.shape[0], x_cl.shape[1]
@@ -677,6 +865,8 @@ class AutoencoderKL1DFastEncode(_HipVAE):
         """Channels-last polylines [G,32,3] -> channels-last latent modes [G,4,3]."""
         dt = self._dtype()
         n = x_cl.shape[0]
+        if self._use_executor():
+            return self._run(x_cl, (x_cl.shape[1] >> len(self.block_out), self.latent), dt)
         worst = x_cl.shape[1] * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
         step = self._chunk(n, worst)
         outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]

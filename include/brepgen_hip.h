@@ -299,6 +299,54 @@ int bg_downsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stre
 int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype, int S, int T, int C, int nh, float scale,
                   bg_stream_t stream);
 
+/* ---- a whole VAE pass as ONE call (bg_vae2d_decode / bg_vae1d_decode; the encoders too).
+ * Replaces AutoencoderKLFastDecode / AutoencoderKL1DFastDecode / ...FastEncode.forward (network.py:690-1040): the four
+ * networks are the same few steps in different orders, so there is one interpreter and the caller hands it the
+ * network as a flat program (brepgen_amd/vae.py builds it once per module and dtype from the state dict).  Every
+ * launch of the pass is enqueued on `stream` by this call; nothing is allocated and nothing synchronises.
+ *
+ * Activations live in SLOTS: fp32 channels-last [S, H, W, C] (1-D: H = 1).  Slot 0 is the caller's input, slot
+ * BG_VAE_OUT the caller's output, slots 1 .. n_slots-1 are carved from the workspace (all the same size: the largest
+ * activation of the program).  A step reads `src` (+ optional residual `res`) and writes `dst` (dst != src, res).
+ *   BG_VOP_CONV          [GroupNorm (+act) ->] conv kh x kw [on the nearest-x2 up-sampled grid: up = 1] [stride 2] + bias
+ *                        [+ res].  pad_mode 0: "same" zero padding (kh/2, kw/2); 1: Downsample2D's F.pad(0,1,0,1), no other.
+ *                        w: [n_pad, kh*kw*C_in] tap-major / channel-minor, dtype w_dtype; columns < n_out are written.
+ *                        Runs as the implicit GEMM bg_conv_gemm_fwd when that kernel's shape rules hold, else
+ *                        bg_im2col + bg_gemm_bias_act_fwd -- the same choice for the same shapes, so results do not
+ *                        depend on how the batch is chunked beyond which of the two a chunk size selects.
+ *   BG_VOP_NORM_ACT_ADD  dst = act(GroupNorm(src)) + res                     (the tail of diffusers' ResConvBlock)
+ *   BG_VOP_ATTN          dst = src + proj(softmax(q k^T * scale) v), q|k|v = GroupNorm(src) w^T + bias ([3C, C] fused),
+ *                        per sample over its H*W tokens with `heads` heads; w2 / bias2 = the output projection
+ *   BG_VOP_UP1D / DOWN1D bg_upsample1d_cubic / bg_downsample1d_cubic
+ * The batch is processed in chunks of `chunk` samples; bg_vae_workspace_bytes(n, chunk) is the workspace that takes. */
+enum bg_vae_opcode { BG_VOP_CONV = 0, BG_VOP_NORM_ACT_ADD = 1, BG_VOP_ATTN = 2, BG_VOP_UP1D = 3, BG_VOP_DOWN1D = 4 };
+enum bg_vae_act { BG_VACT_NONE = 0, BG_VACT_SILU = 1, BG_VACT_GELU = 2 };
+#define BG_VAE_MAX_SLOTS 8
+#define BG_VAE_OUT 255
+typedef struct {
+    int op;                    /* bg_vae_opcode */
+    int src, dst, res;         /* slots; res = -1: none */
+    int kh, kw, up, stride, pad_mode;
+    int n_out, n_pad, w_dtype; /* CONV: output channels, rows of w, BG_F32 | BG_BF16 | BG_F16.  ATTN: n_pad / w_dtype of the q|k|v weights */
+    const void* w;
+    const float* bias;
+    const float* gn_gamma;     /* NULL: no GroupNorm in front */
+    const float* gn_beta;
+    int gn_groups;
+    float gn_eps;
+    int act;                   /* bg_vae_act, applied after the GroupNorm */
+    int heads;                 /* ATTN */
+    float scale;
+    int n_pad2, w2_dtype;
+    const void* w2;
+    const float* bias2;
+} bg_vae_op;
+size_t bg_vae_workspace_bytes(const bg_vae_op* ops, int n_ops, int n_slots, int in_h, int in_w, int in_c, int n, int chunk);
+/* x: [n, in_h, in_w, in_c] fp32; out: [n, Ho, Wo, C_out] fp32 (the shape of the step that writes BG_VAE_OUT);
+ * zero_page: >= 2 * max C bytes of zeros (see bg_conv_desc); workspace 256-byte aligned. */
+int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h, int in_w, int in_c, const float* x, int n, int chunk,
+               float* out, const void* zero_page, void* workspace, size_t workspace_bytes, bg_stream_t stream);
+
 /* ---- bbox de-duplication between the cascade stages, on the device (the reference does it on the host in numpy:
  * sample.py:159-183 faces, 242-261 edges).  Same greedy order-dependent algorithm in float32, incl. the
  * corner-swapped match and (faces) np.round(x, 4); decisions are bit-identical to the numpy code. */

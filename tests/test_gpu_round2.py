@@ -382,3 +382,80 @@ def test_vae_implicit_gemm_equals_materialised_im2col(pc, kind, n, dt):
     assert torch.isfinite(a).all() and torch.equal(a, b)
     e = float((a[:4].cpu() - want).abs().max())
     assert e < (0.15 if dt == BF16 else 0.03) * max(1.0, float(want.abs().max())), e     # the 16-bit VAE tolerance of test_gpu_parity
+
+
+# ---- a whole VAE pass as one C call (bg_vae_run) -------------------------------------------------------------------------
+def _vae_case(pc, kind, n, seed=7):
+    import brepgen_amd as bga
+    from oracle import vae as ov
+    g = torch.Generator().manual_seed(seed)
+    if kind == "surf":
+        sd, m, z = ov.seeded_state_dict(ov.surf_decoder_spec(), 31), bga.AutoencoderKLFastDecode(**pc.SURF_CFG), torch.randn(n, 3, 4, 4, generator=g)
+    elif kind == "edge":
+        sd, m, z = ov.seeded_state_dict(ov.edge_decoder_spec(), 41), bga.AutoencoderKL1DFastDecode(**pc.EDGE_CFG), torch.randn(n, 3, 4, generator=g)
+    elif kind == "surf_enc":
+        sd, m, z = ov.seeded_state_dict(ov.surf_encoder_spec(), 51), bga.AutoencoderKLFastEncode(**pc.SURF_CFG), torch.randn(n, 3, 32, 32, generator=g)
+    else:
+        sd, m, z = ov.seeded_state_dict(ov.edge_encoder_spec(), 61), bga.AutoencoderKL1DFastEncode(**pc.EDGE_CFG), torch.randn(n, 3, 32, generator=g)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), z.cuda()
+
+
+@pytest.mark.parametrize("kind,n", [("surf", 20), ("edge", 96), ("surf_enc", 20), ("edge_enc", 96)])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_vae_program_equals_step_by_step(pc, kind, n, dt):
+    """bg_vae_run interprets the module's flat program with the same primitives, shapes and launch order as the Python
+    step-by-step driver: the results are the same bits (fp32 and bf16, decoders and encoders)."""
+    m, z = _vae_case(pc, kind, n)
+    m.compute_dtype = dt
+    with torch.no_grad():
+        m.executor = True
+        a = m(z)
+        m.executor = False
+        b = m(z)
+    assert a.shape == b.shape and torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind,n", [("surf", 23), ("edge", 101)])
+def test_vae_program_chunks_against_the_workspace_budget(pc, kind, n):
+    """A small WS_BUDGET forces several chunks plus a ragged tail inside the one C call; samples are independent, so in
+    fp32 (one GEMM kernel whatever the chunk size) the chunked pass equals the single-chunk pass bit for bit, and in bf16
+    (a tail chunk may take im2col where the full chunk took the implicit GEMM: same operands, same k order) as well."""
+    m, z = _vae_case(pc, kind, n)
+    lib = __import__("brepgen_amd")._lib.load()
+    for dt in (F32, BF16):
+        m.compute_dtype = dt
+        with torch.no_grad():
+            whole = m(z)
+            pg = m._programs[dt]
+            shape = (4, 4, 3) if kind == "surf" else (1, 4, 3)
+            per = lib.bg_vae_workspace_bytes(pg.ops, len(pg.steps), pg.n_slots, *shape, 7, 7) // 7
+            old, m.WS_BUDGET = m.WS_BUDGET, per * 7 + per // 2           # chunks of 7 samples
+            try:
+                parts = m(z)
+            finally:
+                m.WS_BUDGET = old
+        assert torch.equal(whole, parts), (kind, dt, float((whole - parts).abs().max()))
+
+
+def test_vae_program_rejects_a_small_workspace_and_a_bad_program(pc):
+    import ctypes
+    from brepgen_amd import _lib
+    from brepgen_amd._lib import ptr
+    m, z = _vae_case(pc, "edge", 8)
+    m.compute_dtype = BF16
+    with torch.no_grad():
+        m(z)
+    pg, lib = m._programs[BF16], _lib.load()
+    x = z.permute(0, 2, 1).contiguous()
+    out = torch.empty(8, 32, 3, device="cuda")
+    need = lib.bg_vae_workspace_bytes(pg.ops, len(pg.steps), pg.n_slots, 1, 4, 3, 8, 8)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    zero = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    rc = lib.bg_vae_run(pg.ops, len(pg.steps), pg.n_slots, 1, 4, 3, ptr(x), 8, 8, ptr(out), ptr(zero), ptr(ws), need - 256, None)
+    assert rc == _lib.BG_E_WORKSPACE and b"workspace" in lib.bg_last_error()
+    bad = (_lib.VaeOp * len(pg.steps))(*pg.steps)
+    bad[3].src = 7                                             # a slot no step has written
+    rc = lib.bg_vae_run(bad, len(pg.steps), pg.n_slots, 1, 4, 3, ptr(x), 8, 8, ptr(out), ptr(zero), ptr(ws), need, None)
+    assert rc == _lib.BG_E_ARG and b"step 3" in lib.bg_last_error()
+    torch.cuda.synchronize()

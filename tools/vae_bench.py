@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """VAE decode of BASELINE configs[2]'s output (15 360 faces + 460 800 edges, bf16): convolutions as implicit GEMMs vs the
-materialised im2col path, interleaved.  Random-init weights (the kernels do not care)."""
+materialised im2col path, and the whole pass as one bg_vae_run call vs step by step from Python; interleaved.  Random-init weights (the kernels do not care)."""
 import json
 import os
 import sys
@@ -17,15 +17,19 @@ torch.manual_seed(0)
 surf = bga.AutoencoderKLFastDecode(**SURF_VAE_CFG).cuda().eval()
 edge = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).cuda().eval()
 surf.compute_dtype = edge.compute_dtype = torch.bfloat16
-F_, G_ = (15360, 460800) if len(sys.argv) < 2 else (int(sys.argv[1]), int(sys.argv[2]))
+F_, G_ = (15360, 460800) if len(sys.argv) < 3 else (int(sys.argv[1]), int(sys.argv[2]))
+ONLY = sys.argv[3].split(",") if len(sys.argv) > 3 else None      # e.g. "one_call_program" for a rocprofv3 run
 zs = torch.randn(F_, 48, device="cuda")
 ze = torch.randn(G_, 12, device="cuda")
 FLOP = F_ * 9.69e9 + G_ * 0.416e9
 out = {}
 with torch.no_grad():
     for rnd in range(2):
-        for name, flag in (("implicit_gemm", True), ("im2col", False)):
+        for name, flag, ex in (("one_call_program", True, True), ("implicit_gemm", True, False), ("im2col", False, False)):
+            if ONLY and name not in ONLY:
+                continue
             surf.implicit_gemm = edge.implicit_gemm = flag
+            surf.executor = edge.executor = ex
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             a = surf.decode_tokens(zs)
