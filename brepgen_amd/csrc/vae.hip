@@ -44,6 +44,66 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
+// ---- GroupNorm statistics, many groups per row (G > 1; the 2-D VAE: 32 groups of 4..16 channels): one workgroup per
+// sample streams its rows whole -- every wave reads 1 KiB of consecutive channels -- instead of one wave per group
+// picking 16-byte pieces out of every row.  256 % (C/4) == 0, so a thread always meets the same 4 channels, hence one
+// group.  ONE pass: per-thread sums shifted by the thread's first value (no cancellation against the mean), combined
+// across the threads of a group with the pairwise formula M2 = sum M2_t + sum n_t (mean_t - mean)^2.
+__global__ __launch_bounds__(256) void gn_stats_rows_kernel(const float* __restrict__ x, float* __restrict__ stats, int P, int C,
+                                                            int G, float eps) {
+    __shared__ float sh_n[256], sh_mean[256], sh_m2[256];
+    const int tid = threadIdx.x, s = blockIdx.x;
+    const int c4n = C >> 2, n4 = P * c4n;
+    const float4* __restrict__ base = reinterpret_cast<const float4*>(x + (size_t)s * P * C);
+    float n = 0.f, s1 = 0.f, s2 = 0.f, pivot = 0.f;
+    if (tid < n4) pivot = base[tid].x;
+    int i = tid;
+    for (; i + 768 < n4; i += 1024) {                      // 4 independent 16-byte loads in flight per thread
+        const float4 v0 = base[i], v1 = base[i + 256], v2 = base[i + 512], v3 = base[i + 768];
+        const float4 vs[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a = vs[k].x - pivot, b = vs[k].y - pivot, c = vs[k].z - pivot, d = vs[k].w - pivot;
+            s1 += (a + b) + (c + d);
+            s2 += (a * a + b * b) + (c * c + d * d);
+        }
+        n += 16.f;
+    }
+    for (; i < n4; i += 256) {
+        const float4 v = base[i];
+        const float a = v.x - pivot, b = v.y - pivot, c = v.z - pivot, d = v.w - pivot;
+        s1 += (a + b) + (c + d);
+        s2 += (a * a + b * b) + (c * c + d * d);
+        n += 4.f;
+    }
+    const float mean_t = n > 0.f ? pivot + s1 / n : 0.f;
+    sh_n[tid] = n;
+    sh_mean[tid] = mean_t;
+    sh_m2[tid] = n > 0.f ? s2 - s1 * s1 / n : 0.f;
+    __syncthreads();
+    if (tid < G) {
+        // the threads of group g: c4 = t % c4n in [g q4, (g+1) q4), q4 = (C/G)/4
+        const int q4 = (C / G) >> 2, reps = 256 / c4n;
+        float nt = 0.f, sm = 0.f;
+        for (int r = 0; r < reps; ++r)
+            for (int j = 0; j < q4; ++j) {
+                const int t = r * c4n + tid * q4 + j;
+                nt += sh_n[t];
+                sm += sh_n[t] * sh_mean[t];
+            }
+        const float mean = sm / nt;
+        float m2 = 0.f;
+        for (int r = 0; r < reps; ++r)
+            for (int j = 0; j < q4; ++j) {
+                const int t = r * c4n + tid * q4 + j;
+                const float d = sh_mean[t] - mean;
+                m2 += sh_m2[t] + sh_n[t] * d * d;
+            }
+        stats[((size_t)s * G + tid) * 2 + 0] = mean;
+        stats[((size_t)s * G + tid) * 2 + 1] = 1.0f / sqrtf(m2 / nt + eps);
+    }
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return silu_f(v);
     if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));    // nn.GELU() (erf form)
@@ -100,6 +160,49 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
     }
 }
 
+// The 1x1 window on the same grid (no gather at all): out = act(GroupNorm(x)) (+ add), cast.  This is the pass in front
+// of every implicit-GEMM convolution, the tail of ResConvBlock and the pre-norm of the mid-block attention -- the
+// general kernel above spends more issue slots on its 64-bit index arithmetic than the HBM stream leaves room for.
+// Flat 32-bit index over the float4 elements; same per-element arithmetic as im2col_kernel (bit-identical results).
+__global__ __launch_bounds__(256) void norm_act_kernel(Im2colArgs a, unsigned total4, unsigned n4s, unsigned c4n) {
+    const unsigned cpg4 = a.stats ? (unsigned)(a.C / a.G) >> 2 : 1u;
+    const bool pow2 = (c4n & (c4n - 1)) == 0;
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
+    const unsigned i0 = blockIdx.x * 1024u + threadIdx.x;
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = i0 + k * 256u;
+        if (i < total4) v[k] = x4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = i0 + k * 256u;
+        if (i >= total4) continue;
+        float4 w = v[k];
+        const unsigned c4 = pow2 ? (i & (c4n - 1)) : (i % c4n);
+        if (a.stats) {
+            const unsigned smp = i / n4s;
+            const float2 st = *reinterpret_cast<const float2*>(a.stats + ((size_t)smp * a.G + c4 / cpg4) * 2);
+            const float mean = st.x, rstd = st.y;
+            const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c4 * 4);
+            const float4 be = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
+            w.x = (w.x - mean) * rstd * ga.x + be.x;
+            w.y = (w.y - mean) * rstd * ga.y + be.y;
+            w.z = (w.z - mean) * rstd * ga.z + be.z;
+            w.w = (w.w - mean) * rstd * ga.w + be.w;
+        }
+        w.x = act_apply(w.x, a.act); w.y = act_apply(w.y, a.act);
+        w.z = act_apply(w.z, a.act); w.w = act_apply(w.w, a.act);
+        if (a.add) {
+            const float4 ad = reinterpret_cast<const float4*>(a.add)[i];
+            w.x += ad.x; w.y += ad.y; w.z += ad.z; w.w += ad.w;
+        }
+        if (a.out_dtype != BG_F32) reinterpret_cast<uint2*>(a.out)[i] = pack4_16(w.x, w.y, w.z, w.w, a.out_dtype);
+        else reinterpret_cast<float4*>(a.out)[i] = w;
+    }
+}
+
 // any C (the 3-channel latent inputs of post_quant_conv / conv_in), no norm, fp32 out
 __global__ __launch_bounds__(256) void im2col_scalar_kernel(Im2colArgs a) {
     const int H = a.Hin << a.up, W = a.Win << a.up, taps = a.kh * a.kw;
@@ -144,6 +247,30 @@ __global__ __launch_bounds__(256) void upsample1d_cubic_kernel(const float* __re
         }
         y[i] = acc;
     }
+}
+
+// the same for 4 consecutive channels per thread, 32-bit index arithmetic (C % 4 == 0 and < 2^32 elements: every call of
+// the edge decoder); per channel the same fmaf chain in the same order as the scalar kernel
+__global__ __launch_bounds__(256) void upsample1d_cubic4_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned total4,
+                                                                unsigned L, unsigned c4n) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned c4 = i % c4n, r = i / c4n;
+    const unsigned o = r % (2 * L), s = r / (2 * L);
+    const float4* __restrict__ xs = reinterpret_cast<const float4*>(x) + (size_t)s * L * c4n + c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int i0 = (int)(o + 1) >> 1, i1 = (int)(o + 7) >> 1;
+    for (int ii = i0; ii <= i1; ++ii) {
+        const int kk = (int)o + 7 - 2 * ii;
+        if (kk < 0 || kk > 7 || ii > (int)L + 3) continue;
+        int j = ii - 2;
+        j = j < 0 ? -j : (j >= (int)L ? 2 * ((int)L - 1) - j : j);
+        const float4 v = xs[(size_t)j * c4n];
+        const float w = kCubic2[kk];
+        acc.x = fmaf(v.x, w, acc.x); acc.y = fmaf(v.y, w, acc.y);
+        acc.z = fmaf(v.z, w, acc.z); acc.w = fmaf(v.w, w, acc.w);
+    }
+    reinterpret_cast<float4*>(y)[i] = acc;
 }
 
 // ---- Downsample1d("cubic") of the edge encoder (diffusers DownBlock1D): reflect-pad 3, depthwise stride-2 conv with
@@ -205,6 +332,52 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict
     }
 }
 
+// the same with the sample's q|k|v rows staged in LDS by coalesced 16-byte loads first (the edge VAE: 4 tokens x 1536
+// floats = 24 KiB per sample; the strided scalar reads of the kernel above ran at a quarter of the HBM rate).  Same
+// fmaf chains in the same order: bit-identical results.
+__global__ __launch_bounds__(256) void small_attn_lds_kernel(const float* __restrict__ qkv, int ld, void* __restrict__ out,
+                                                             int out_dtype, int T, int C, int nh, float scale) {
+    extern __shared__ float sm[];                           // [T][3C] rows | [nh][T][T] scores
+    const int s = blockIdx.x, d = C / nh, n_sc = nh * T * T, w4 = (3 * C) >> 2;
+    float* sc = sm + (size_t)T * 3 * C;
+    const float* base = qkv + (size_t)s * T * ld;
+    for (int e = threadIdx.x; e < T * w4; e += blockDim.x) {
+        const int row = e / w4, c4 = e - row * w4;
+        reinterpret_cast<float4*>(sm)[e] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + c4 * 4);
+    }
+    __syncthreads();
+    const int W = 3 * C;
+    for (int e = threadIdx.x; e < n_sc; e += blockDim.x) {
+        const int j = e % T, i = (e / T) % T, hh = e / (T * T);
+        const float* q = sm + i * W + hh * d;
+        const float* k = sm + j * W + C + hh * d;
+        float acc = 0.f;
+        for (int t = 0; t < d; ++t) acc = fmaf(q[t], k[t], acc);
+        sc[e] = acc * scale;
+    }
+    __syncthreads();
+    for (int row = threadIdx.x; row < nh * T; row += blockDim.x) {
+        float* p = sc + (size_t)row * T;
+        float m = -INFINITY;
+        for (int j = 0; j < T; ++j) m = fmaxf(m, p[j]);
+        float l = 0.f;
+        for (int j = 0; j < T; ++j) { p[j] = expf(p[j] - m); l += p[j]; }
+        const float inv = 1.0f / l;
+        for (int j = 0; j < T; ++j) p[j] *= inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * C; e += blockDim.x) {
+        const int col = e % C, i = e / C, hh = col / d;
+        const float* p = sc + ((size_t)hh * T + i) * T;
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc = fmaf(p[j], sm[j * W + 2 * C + col], acc);
+        const size_t o = ((size_t)s * T + i) * C + col;
+        if (out_dtype == BG_BF16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)acc;
+        else if (out_dtype == BG_F16) reinterpret_cast<_Float16*>(out)[o] = (_Float16)acc;
+        else reinterpret_cast<float*>(out)[o] = acc;
+    }
+}
+
 static inline int cap_grid(size_t work) {
     const size_t b = (work + 255) / 256;
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
@@ -218,7 +391,11 @@ extern "C" int bg_groupnorm_stats(const float* x, float* stats, int S, int P, in
     BG_REQUIRE(S > 0 && P > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0, BG_E_SHAPE,
                "bg_groupnorm_stats: need C %% G == 0 and (C/G) %% 4 == 0 (S=%d P=%d C=%d G=%d)", S, P, C, G);
     bg::ProfScope prof(bg::PK_MISC, 0.0, 8.0 * S * (double)P * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bg::gn_stats_kernel, dim3((S * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, stats, S, P, C, G, eps);
+    const int c4n = C / 4;
+    if (G > 1 && G <= 256 && c4n <= 256 && 256 % c4n == 0 && (long long)P * c4n >= 256)
+        hipLaunchKernelGGL(bg::gn_stats_rows_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, x, stats, P, C, G, eps);
+    else
+        hipLaunchKernelGGL(bg::gn_stats_kernel, dim3((S * G + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, stats, S, P, C, G, eps);
     return bg::launch_status("groupnorm_stats");
 }
 
@@ -236,7 +413,12 @@ extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hi
     const size_t rows = (size_t)S * Ho * Wo;
     bg::ProfScope prof(bg::PK_MISC, 0.0, rows * (double)kh * kw * C * (4.0 + (out_dtype == BG_F32 ? 4.0 : 2.0)),
                        (hipStream_t)stream);
-    if (C % 4 == 0) {
+    const unsigned long long total4 = rows * (unsigned long long)(C / 4);
+    if (C % 4 == 0 && kh == 1 && kw == 1 && up == 0 && stride == 1 && pad_y == 0 && pad_x == 0 && Ho == Hin && Wo == Win &&
+        total4 < (1ull << 32) - 1024) {
+        hipLaunchKernelGGL(bg::norm_act_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a,
+                           (unsigned)total4, (unsigned)((size_t)Hin * Win * (C / 4)), (unsigned)(C / 4));
+    } else if (C % 4 == 0) {
         hipLaunchKernelGGL(bg::im2col_kernel, dim3(bg::cap_grid(rows * kh * kw * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         BG_REQUIRE(stats == nullptr, BG_E_SHAPE, "bg_im2col: normalised input needs C %% 4 == 0");
@@ -248,8 +430,13 @@ extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hi
 extern "C" int bg_upsample1d_cubic(const float* x, float* y, int S, int L, int C, bg_stream_t stream) {
     BG_REQUIRE(x && y && S > 0 && L >= 3 && C > 0, BG_E_ARG, "bg_upsample1d_cubic: bad arguments (reflect pad needs L >= 3)");
     bg::ProfScope prof(bg::PK_MISC, 0.0, 12.0 * S * (double)L * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bg::upsample1d_cubic_kernel, dim3(bg::cap_grid((size_t)S * 2 * L * C)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, S, L, C);
+    const unsigned long long total4 = (unsigned long long)S * 2 * L * (C / 4);
+    if (C % 4 == 0 && total4 < (1ull << 32) - 256)
+        hipLaunchKernelGGL(bg::upsample1d_cubic4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                           (unsigned)total4, (unsigned)L, (unsigned)(C / 4));
+    else
+        hipLaunchKernelGGL(bg::upsample1d_cubic_kernel, dim3(bg::cap_grid((size_t)S * 2 * L * C)), dim3(256), 0, (hipStream_t)stream,
+                           x, y, S, L, C);
     return bg::launch_status("upsample1d_cubic");
 }
 
@@ -267,7 +454,12 @@ extern "C" int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype,
     BG_REQUIRE(nh * T * T <= 8192, BG_E_SHAPE, "bg_small_attn: nh*T*T = %d exceeds the LDS score buffer", nh * T * T);
     BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_small_attn: out dtype %d", out_dtype);
     bg::ProfScope prof(bg::PK_MISC, 4.0 * S * (double)T * T * C, 16.0 * S * (double)T * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bg::small_attn_kernel, dim3(S), dim3(256), (size_t)nh * T * T * sizeof(float), (hipStream_t)stream, qkv, ld,
-                       out, out_dtype, T, C, nh, scale);
+    const size_t staged = ((size_t)T * 3 * C + (size_t)nh * T * T) * sizeof(float);
+    if (staged <= 40 * 1024 && C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)qkv & 15) == 0)        // >= 4 workgroups per CU
+        hipLaunchKernelGGL(bg::small_attn_lds_kernel, dim3(S), dim3(256), staged, (hipStream_t)stream, qkv, ld, out, out_dtype, T, C,
+                           nh, scale);
+    else
+        hipLaunchKernelGGL(bg::small_attn_kernel, dim3(S), dim3(256), (size_t)nh * T * T * sizeof(float), (hipStream_t)stream, qkv, ld,
+                           out, out_dtype, T, C, nh, scale);
     return bg::launch_status("small_attn");
 }
