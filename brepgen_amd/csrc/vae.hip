@@ -118,20 +118,22 @@ struct Im2colArgs {
     const float* add;        // optional residual, added after norm + activation (1x1 / fp32-out use only)
 };
 
-// one thread = 4 consecutive channels of one (row, tap)
+// one thread = 4 consecutive channels of one (row, tap).  IDX = unsigned whenever the element count allows it: the index
+// arithmetic is seven divisions per 16 bytes moved, and 64-bit ones cost more issue slots than the HBM stream leaves.
+template <typename IDX>
 __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
     const int H = a.Hin << a.up, W = a.Win << a.up;       // logical input grid
-    const int c4n = a.C >> 2, taps = a.kh * a.kw;
-    const size_t total = (size_t)a.S * a.Ho * a.Wo * taps * c4n;
+    const IDX c4n = (IDX)(a.C >> 2), taps = (IDX)(a.kh * a.kw), Wo = (IDX)a.Wo, Ho = (IDX)a.Ho;
+    const IDX total = (IDX)a.S * Ho * Wo * taps * c4n;
     const int cpg = a.stats ? a.C / a.G : 1;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    for (IDX i = blockIdx.x * (IDX)blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % c4n);
-        size_t r = i / c4n;
+        IDX r = i / c4n;
         const int tap = (int)(r % taps);
         r /= taps;                                            // row = (s, oy, ox)
-        const int ox = (int)(r % a.Wo);
-        const size_t r2 = r / a.Wo;
-        const int oy = (int)(r2 % a.Ho), s = (int)(r2 / a.Ho);
+        const int ox = (int)(r % Wo);
+        const IDX r2 = r / Wo;
+        const int oy = (int)(r2 % Ho), s = (int)(r2 / Ho);
         const int iy = oy * a.stride + tap / a.kw - a.pad_y, ix = ox * a.stride + tap % a.kw - a.pad_x;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
             v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act);
             v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act);
         }
-        const size_t o = (r * taps + tap) * (size_t)a.C + c4 * 4;
+        const size_t o = (size_t)i * 4;                       // == ((row * taps + tap) * C + c4 * 4)
         if (a.add) {
             const float4 ad = *reinterpret_cast<const float4*>(a.add + o);
             v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
@@ -419,7 +421,11 @@ extern "C" int bg_im2col(const float* x, void* out, int out_dtype, int S, int Hi
         hipLaunchKernelGGL(bg::norm_act_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a,
                            (unsigned)total4, (unsigned)((size_t)Hin * Win * (C / 4)), (unsigned)(C / 4));
     } else if (C % 4 == 0) {
-        hipLaunchKernelGGL(bg::im2col_kernel, dim3(bg::cap_grid(rows * kh * kw * (C / 4))), dim3(256), 0, (hipStream_t)stream, a);
+        const unsigned long long work = (unsigned long long)rows * kh * kw * (C / 4);
+        if (work < (1ull << 32) - (1ull << 22))               // grid stride 8192 x 256 = 2^21: no wrap-around of the 32-bit index
+            hipLaunchKernelGGL(bg::im2col_kernel<unsigned>, dim3(bg::cap_grid(work)), dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(bg::im2col_kernel<size_t>, dim3(bg::cap_grid(work)), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         BG_REQUIRE(stats == nullptr, BG_E_SHAPE, "bg_im2col: normalised input needs C %% 4 == 0");
         hipLaunchKernelGGL(bg::im2col_scalar_kernel, dim3(bg::cap_grid(rows * kh * kw * C)), dim3(256), 0, (hipStream_t)stream, a);

@@ -213,9 +213,22 @@ class CascadeSampler:
 
     @torch.no_grad()
     def sample(self, batch_size, num_surfaces, num_edges, generator=None, device="cuda",
-               pndm_pos_steps=158, ddpm_pos_steps=250, pndm_z_steps=None, stop_after=None, gather=True):
+               pndm_pos_steps=158, ddpm_pos_steps=250, pndm_z_steps=None, stop_after=None, gather=True, timings=None):
         """-> dict of latents: the whole batch on every rank (gather=True), or this rank's rows only (gather=False;
-        pass them -- plus anything derived per sample, e.g. the VAE decode -- to `gather_latents(..., batch_size=)`)."""
+        pass them -- plus anything derived per sample, e.g. the VAE decode -- to `gather_latents(..., batch_size=)`).
+        timings: a dict to receive the wall-clock seconds of each stage (adds one device synchronisation per stage)."""
+        import time
+        clock = [None]
+
+        def mark(stage):
+            if timings is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                if stage is not None:
+                    timings[stage] = now - clock[0]
+                clock[0] = now
+
+        mark(None)
         surfpos_net, surfz_net, edgepos_net, edgez_net = self.nets
         dev = torch.device(device)
         lo, hi = shard_range(batch_size, self.rank, self.world)
@@ -268,6 +281,7 @@ class CascadeSampler:
                 x = self._step(self.ddpm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t, noise=z)
             surfPos, surfMask = dedup_surfaces(x, self.thr)
             out = {"surfPos": surfPos, "surfMask": surfMask}
+            mark("surfPos")
             if stop_after == "surfPos":
                 return finish(out)
 
@@ -282,6 +296,7 @@ class CascadeSampler:
                 surfZ = self._step(self.pndm, lambda g: surfz_net(self._rep(surfZ, 2) if g else surfZ, td, sp2, sm2, cl),
                                    surfZ, t)
             out["surfZ"] = surfZ
+            mark("surfZ")
             if stop_after == "surfZ":
                 return finish(out)
 
@@ -306,6 +321,7 @@ class CascadeSampler:
                                                                        sz2, sm2, cl), edgePos, t, noise=z)
             edgeM = dedup_edges(edgePos, surfMask, self.thr)
             out.update(edgePos=edgePos, edgeM=edgeM)
+            mark("edgePos")
             if stop_after == "edgePos":
                 return finish(out)
 
@@ -321,4 +337,5 @@ class CascadeSampler:
                                                                     sz2, em2, cl), edgeZV, t)
             edgeZV = edgeZV.masked_fill(edgeM.unsqueeze(-1), 0.0)   # sample.py:284
             out["edgeZV"] = edgeZV
+            mark("edgeZV")
         return finish(out)
