@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the measurements reported beside the headline")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + JSON only, on CPU (no compute)")
     ap.add_argument("--dense", action="store_true", help="run every padded position like the reference (no compaction)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 "
+                                                              "(exercises the collective path on a 1-GPU box)")
     ap.add_argument("--split", type=int, default=0, help="sample groups run concurrently on forked streams (0 = the "
                                                          "module's default: 2 at this batch size; 1 = off)")
     args = ap.parse_args()
@@ -308,9 +310,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import brepgen_amd as bga
@@ -351,11 +354,11 @@ def main():
 
     x = run_steps(args.warmup, z)
     if dist is not None:
-        gather_latents({"surfZ": x}, dist)                           # warm the communicator up outside the clock
+        gather_latents({"surfZ": x}, dist, single_rank_collective=args.force_dist)   # warm the communicator up outside the clock
     barrier()
     t0 = time.perf_counter()
     x = run_steps(args.steps, x, args.warmup)
-    out = gather_latents({"surfZ": x}, dist) if dist is not None else {"surfZ": x}
+    out = gather_latents({"surfZ": x}, dist, single_rank_collective=args.force_dist) if dist is not None else {"surfZ": x}
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -124,8 +124,9 @@ def main(argv=None):
     dist = None
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")                                                     # RCCL over xGMI
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)                                                        # before the communicator exists
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))              # RCCL over xGMI
     autocast = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32": False}[a.dtype]
     sampler, surf_vae, edge_vae = build(eval_args, "cuda", dist, autocast, a.weights)
     rank = dist.get_rank() if dist is not None else 0

@@ -56,15 +56,16 @@ def device_randn(shape, seed, draw_id, first_sample, device):
     return out
 
 
-def gather_latents(tensors, dist=None, group=None, batch_size=None):
+def gather_latents(tensors, dist=None, group=None, batch_size=None, single_rank_collective=False):
     """All-gather a dict of per-rank tensors (this rank's `shard_range` rows of a batch of `batch_size`, batch on
     dim 0) with ONE collective; returns the dict with the full batch on every rank.
 
     Everything is packed into one flat byte buffer (bool / uint8 / fp32 alike) so the ring runs once with a large
     message instead of once per tensor.  Ranks may own different numbers of rows (or none): every rank pads its rows
     to ceil(batch_size / world) before the collective -- all_gather needs equal contributions -- and the padding is
-    trimmed with `shard_range` afterwards.  batch_size=None means equal shards (world * local rows)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    trimmed with `shard_range` afterwards.  batch_size=None means equal shards (world * local rows).
+    single_rank_collective: run the pack -> all_gather -> unpack path even with one rank (how a 1-GPU box tests the RCCL leg)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not single_rank_collective):
         return dict(tensors)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     names = sorted(tensors)

@@ -459,3 +459,22 @@ def test_vae_program_rejects_a_small_workspace_and_a_bad_program(pc):
     rc = lib.bg_vae_run(bad, len(pg.steps), pg.n_slots, 1, 4, 3, ptr(x), 8, 8, ptr(out), ptr(zero), ptr(ws), need, None)
     assert rc == _lib.BG_E_ARG and b"step 3" in lib.bg_last_error()
     torch.cuda.synchronize()
+
+
+# ---- the RCCL leg of bench.py on one GPU ---------------------------------------------------------------------------------
+def test_bench_collective_path_runs_on_rccl(pc):
+    """`bench.py --force-dist`: the process group (backend nccl = RCCL, device-bound), the barrier, the all_gather of the
+    latents inside the timed region and the max-over-ranks all_reduce, with world size 1 -- all a 1-GPU box can run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist",
+                        "--no-extra", "--no-roofline", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["finite"]
