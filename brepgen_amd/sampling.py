@@ -158,18 +158,50 @@ def decode_latents(surf_vae, edge_vae, latents):
     return out
 
 
+class _GraphedEval:
+    """One eps-evaluation captured into a hipGraph (via torch.cuda.graph): static latent / timestep buffers, one graph launch
+    per step instead of ~90 kernel launches.  Everything else the evaluation reads (bbox / latent conditioning, masks, class
+    labels) is captured by address and must stay alive and unchanged for the stage -- which is how the cascade uses it."""
+
+    def __init__(self, fn, x, td):
+        self.x, self.td = x.clone(), td.clone()
+        cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fn(self.x, self.td)                      # outside the capture: weight packing, workspace sizing
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn(self.x, self.td)
+
+    def __call__(self, x, td):
+        self.x.copy_(x)
+        self.td.copy_(td)
+        self.graph.replay()
+        return self.out                              # consumed by the scheduler step before the next replay (same stream)
+
+
 class CascadeSampler:
     """Runs stages 1-4 of sample.py on this rank's slice of the batch and (by default) all-gathers the latents.
 
     noise_mode: "device" (default) -- ancestral DDPM noise from the counter-based device generator, keyed on the global
     sample index (reproducible for any number of ranks); "reference" -- whole-batch draw from the seeded CPU generator at
     every step, sliced by rank (the reference's utils.randn_tensor semantics; what a CPU-driven oracle cascade can
-    reproduce bit for bit, at the price of B x S x E x 6 host randoms and a PCIe copy per step on every rank)."""
+    reproduce bit for bit, at the price of B x S x E x 6 host randoms and a PCIe copy per step on every rank).
+
+    graphs: "auto" (default) -- stages whose eps-evaluation is launch-bound (<= GRAPH_MAX_TOKENS tokens: every stage at
+    the reference's batch 16, the surface stages up to a few hundred samples) replay ONE captured hipGraph per step;
+    True / False force it on / off.  Same kernels in the same order: results are bit-identical either way."""
+
+    GRAPH_MAX_TOKENS = 32768
 
     def __init__(self, surfpos, surfz, edgepos, edgez, pndm, ddpm, *, use_cf=False, class_id=0, guidance=0.6,
-                 bbox_threshold=0.08, dist=None, autocast=True, noise_mode="device"):
+                 bbox_threshold=0.08, dist=None, autocast=True, noise_mode="device", graphs="auto"):
         if noise_mode not in ("device", "reference"):
             raise ValueError("noise_mode must be 'device' or 'reference'")
+        if graphs not in ("auto", True, False):
+            raise ValueError("graphs must be 'auto', True or False")
+        self.graphs = graphs
         self.nets = (surfpos, surfz, edgepos, edgez)
         self.pndm, self.ddpm = pndm, ddpm
         self.use_cf, self.class_id, self.w = use_cf, class_id, guidance
@@ -186,6 +218,14 @@ class CascadeSampler:
             eps = net_call(True)
             return sched.step(eps, t, x, guidance=self.w, **kw).prev_sample
         return sched.step(net_call(False), t, x, **kw).prev_sample
+
+    def _evaluator(self, fn, x, td):
+        """fn(latent, timestep) -> eps, as is or captured into a graph (x / td: example inputs of the stage)."""
+        tokens = x.numel() // max(1, x.shape[-1]) * (2 if self.use_cf else 1)
+        use = self.graphs is True or (self.graphs == "auto" and tokens <= self.GRAPH_MAX_TOKENS)
+        if not use or x.shape[0] == 0:
+            return fn
+        return _GraphedEval(fn, self._rep(x, 2) if self.use_cf else x, td)
 
     def _labels(self, b, device):
         if not self.use_cf:
@@ -263,23 +303,26 @@ class CascadeSampler:
             x = sharded_randn((batch_size, S, 6), generator, self.rank, self.world, dev)
             self.pndm.set_timesteps(200)
             pndm_ts, pndm_dev = self.pndm.timesteps, self.pndm.timesteps.to(dev)     # ONE copy; steps take views
+            ev = None if skip else self._evaluator(lambda xi, ti: surfpos_net(xi, ti, cl), x, pndm_dev[:1])
             for i, t in enumerate(pndm_ts[:pndm_pos_steps]):
                 if skip:
                     break
                 td = pndm_dev[i:i + 1]
-                x = self._step(self.pndm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t)
+                x = self._step(self.pndm, lambda g: ev(self._rep(x, 2) if g else x, td), x, t)
             if not self.use_cf:                                     # late doubling, sample.py:140-142
                 x = x.repeat(1, 2, 1).contiguous()
                 S *= 2
             self.ddpm.set_timesteps(1000)
             ddpm_ts = self.ddpm.timesteps[-ddpm_pos_steps:]
             ddpm_dev = ddpm_ts.to(dev)
+            if not skip and not self.use_cf:                        # the token count doubled: a new capture
+                ev = self._evaluator(lambda xi, ti: surfpos_net(xi, ti, cl), x, ddpm_dev[:1])
             for i, t in enumerate(ddpm_ts):
                 z = ancestral((S, 6), t)
                 if skip:
                     continue
                 td = ddpm_dev[i:i + 1]
-                x = self._step(self.ddpm, lambda g: surfpos_net(self._rep(x, 2) if g else x, td, cl), x, t, noise=z)
+                x = self._step(self.ddpm, lambda g: ev(self._rep(x, 2) if g else x, td), x, t, noise=z)
             surfPos, surfMask = dedup_surfaces(x, self.thr)
             out = {"surfPos": surfPos, "surfMask": surfMask}
             mark("surfPos")
@@ -290,12 +333,12 @@ class CascadeSampler:
             surfZ = sharded_randn((batch_size, S, 48), generator, self.rank, self.world, dev)
             sp2, sm2 = (self._rep(surfPos, 2), self._rep(surfMask, 2)) if self.use_cf else (surfPos, surfMask)
             self.pndm.set_timesteps(200)
+            ev = None if skip else self._evaluator(lambda xi, ti: surfz_net(xi, ti, sp2, sm2, cl), surfZ, pndm_dev[:1])
             for i, t in enumerate(pndm_ts[:pndm_z_steps]):
                 if skip:
                     break
                 td = pndm_dev[i:i + 1]
-                surfZ = self._step(self.pndm, lambda g: surfz_net(self._rep(surfZ, 2) if g else surfZ, td, sp2, sm2, cl),
-                                   surfZ, t)
+                surfZ = self._step(self.pndm, lambda g: ev(self._rep(surfZ, 2) if g else surfZ, td), surfZ, t)
             out["surfZ"] = surfZ
             mark("surfZ")
             if stop_after == "surfZ":
@@ -306,20 +349,19 @@ class CascadeSampler:
             edgePos = sharded_randn((batch_size, S, E, 6), generator, self.rank, self.world, dev)
             sz2 = self._rep(surfZ, 2) if self.use_cf else surfZ
             self.pndm.set_timesteps(200)
+            ev = None if skip else self._evaluator(lambda xi, ti: edgepos_net(xi, ti, sp2, sz2, sm2, cl), edgePos, pndm_dev[:1])
             for i, t in enumerate(pndm_ts[:pndm_pos_steps]):
                 if skip:
                     break
                 td = pndm_dev[i:i + 1]
-                edgePos = self._step(self.pndm, lambda g: edgepos_net(self._rep(edgePos, 2) if g else edgePos, td, sp2,
-                                                                       sz2, sm2, cl), edgePos, t)
+                edgePos = self._step(self.pndm, lambda g: ev(self._rep(edgePos, 2) if g else edgePos, td), edgePos, t)
             self.ddpm.set_timesteps(1000)
             for i, t in enumerate(ddpm_ts):
                 z = ancestral((S, E, 6), t)
                 if skip:
                     continue
                 td = ddpm_dev[i:i + 1]
-                edgePos = self._step(self.ddpm, lambda g: edgepos_net(self._rep(edgePos, 2) if g else edgePos, td, sp2,
-                                                                       sz2, sm2, cl), edgePos, t, noise=z)
+                edgePos = self._step(self.ddpm, lambda g: ev(self._rep(edgePos, 2) if g else edgePos, td), edgePos, t, noise=z)
             edgeM = dedup_edges(edgePos, surfMask, self.thr)
             out.update(edgePos=edgePos, edgeM=edgeM)
             mark("edgePos")
@@ -330,12 +372,12 @@ class CascadeSampler:
             edgeZV = sharded_randn((batch_size, S, E, 18), generator, self.rank, self.world, dev)
             ep2, em2 = (self._rep(edgePos, 2), self._rep(edgeM, 2)) if self.use_cf else (edgePos, edgeM)
             self.pndm.set_timesteps(200)
+            ev = None if skip else self._evaluator(lambda xi, ti: edgez_net(xi, ti, ep2, sp2, sz2, em2, cl), edgeZV, pndm_dev[:1])
             for i, t in enumerate(pndm_ts[:pndm_z_steps]):
                 if skip:
                     break
                 td = pndm_dev[i:i + 1]
-                edgeZV = self._step(self.pndm, lambda g: edgez_net(self._rep(edgeZV, 2) if g else edgeZV, td, ep2, sp2,
-                                                                    sz2, em2, cl), edgeZV, t)
+                edgeZV = self._step(self.pndm, lambda g: ev(self._rep(edgeZV, 2) if g else edgeZV, td), edgeZV, t)
             edgeZV = edgeZV.masked_fill(edgeM.unsqueeze(-1), 0.0)   # sample.py:284
             out["edgeZV"] = edgeZV
             mark("edgeZV")

@@ -150,7 +150,7 @@ def _rank_main(rank, world, port, B, S, E, noise_mode, q):
     try:
         sampler = _build_sampler(dist, False, noise_mode)
         out = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(31), **SCHED)
-        q.put((rank, {k: v.cpu() for k, v in out.items()}))
+        q.put((rank, {k: v.cpu().numpy().copy() for k, v in out.items()}))     # by value: no handle to fetch from an exited process
     finally:
         dist.destroy_process_group()
 
@@ -171,7 +171,7 @@ def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, B, S, E, noise_mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(world))
+    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=600) for _ in range(world))}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -41,7 +41,9 @@ def _worker(rank, world, port, B, q):
         a = _stage(sharded_randn((B, 6, 5), g, rank, world, "cpu"))
         b = _stage(sharded_randn((B, 6, 3, 4), g, rank, world, "cpu"))
         out = gather_latents({"a": a, "b": b, "m": a[..., 0] > 0}, dist)
-        q.put((rank, {k: v.clone() for k, v in out.items()}))
+        # by value (numpy pickles its bytes): a torch tensor travels as a shared-memory handle the parent has to fetch from
+        # this process, which may have exited by then
+        q.put((rank, {k: v.numpy().copy() for k, v in out.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -55,7 +57,7 @@ def test_two_rank_gloo_run_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(world))
+    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=300) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

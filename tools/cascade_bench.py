@@ -19,6 +19,7 @@ from brepgen_amd.sampling import CascadeSampler, decode_latents
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 DATALIKE = len(sys.argv) > 2 and sys.argv[2] == "datalike"
+GRAPHS = {"graphs": True, "nographs": False}.get(sys.argv[3] if len(sys.argv) > 3 else "", "auto")
 S, E = 30, 30                                                        # eval_config.yaml: deepcad
 torch.manual_seed(0)
 dev = torch.device("cuda")
@@ -27,7 +28,7 @@ surf_vae = bga.AutoencoderKLFastDecode(**SURF_VAE_CFG).to(dev).eval()
 edge_vae = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).to(dev).eval()
 surf_vae.compute_dtype = edge_vae.compute_dtype = torch.bfloat16
 sampler = CascadeSampler(*nets, bga.PNDMScheduler(**SCHED_KW), bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **SCHED_KW),
-                         bbox_threshold=0.08, autocast=True)
+                         bbox_threshold=0.08, autocast=True, graphs=GRAPHS)
 
 
 if DATALIKE:
@@ -66,7 +67,7 @@ stages = {k: round(v, 3) for k, v in stages.items()}
 finite = all(bool(torch.isfinite(v).all()) for v in dec.values() if v.is_floating_point())
 print(json.dumps({"workload": f"DeepCAD cascade, batch {B}, {S}x2 faces x {E} edges, bf16, random-init weights"
                               + (", SYNTHETIC data-like validity masks" if DATALIKE else ""),
-                  "stage_s": stages, "vae_decode_s": round(t_dec, 3), "cascade_s": round(t_cas, 3),
+                  "graphs": GRAPHS, "stage_s": stages, "vae_decode_s": round(t_dec, 3), "cascade_s": round(t_cas, 3),
                   "total_s": round(t_cas + t_dec, 3), "samples_per_s": round(B / (t_cas + t_dec), 2),
                   "valid_faces_mean": round(float((~lat["surfMask"]).sum(1).float().mean()), 2),
                   "valid_edges_mean_per_sample": round(float((~lat["edgeM"]).sum((1, 2)).float().mean()), 1),
