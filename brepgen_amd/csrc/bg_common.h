@@ -34,7 +34,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 };
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
-enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_COUNT = 8 };
+enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_COUNT = 10 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------

@@ -340,7 +340,8 @@ enum { P_PLAIN16 = 0, P_FOLD16 = 1, P_GENERAL = 2, P_SPLIT = 3 };
 constexpr int FOLD_PARTS = 12;      // the persistent kernel's LayerNorm fold is compiled for K = 768 (LN width of the denoisers)
 
 template <bool F16, int MODE, bool INSTR, bool CONV = false>      // CONV: the A operand is gathered from a conv window (implicit GEMM)
-__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg) {
+__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg,
+                                                                   int stagger = 0) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     using E = Elem<F16>;
     using T = typename E::T;
@@ -467,6 +468,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     // ADJACENT column tiles of one row panel, so the partner's A lines are already in the CU's vector L1
     const int t_first = (walk == 2 && (cnt & 1) == 0) ? ((w_local % (cnt >> 1)) << 1) + (w_local / (cnt >> 1)) : w_local;
     if (!tile_at(t_first, m0, n0)) return;
+    // Phase offset between the two workgroups of a CU (blocks b and b + G/2 share one: tools/cu_census.hip).  Launched
+    // together with identical work they run in lock-step -- both in their K loops, then both in their epilogues -- and the
+    // epilogue's store traffic never hides under the partner's MFMAs.  The second half of the grid therefore starts
+    // `stagger` x 64 cycles late (about half a tile), once per launch; the offset persists over the tile walk.
+    if (stagger > 0 && (int)blockIdx.x >= (G >> 1)) {
+        for (int r = stagger; r > 0; r -= 127) __builtin_amdgcn_s_sleep(127);
+    }
     set_src(m0, n0);
     issue(0, 0);
     int slot = 0;
@@ -827,21 +835,24 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (n128 % ng != 0 || (ng != 1 && ng != 2 && ng != 4 && ng != 8)) ng = 1;
         const bool fast = g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.out_lo == nullptr;
         unsigned long long* none = nullptr;
+        // phase offset of the second workgroup of every CU (bg_tune key 8: sleep units of 64 cycles; 0 = off), only when a
+        // workgroup walks enough tiles for the one-off delay to pay
+        const int stg = (grid == 512 && nt >= 4 * 512) ? g_tune[TUNE_GEMM_STAGGER] : 0;
         if (variant == 31 && g.out_lo == nullptr && g.stats_in == nullptr) {   // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
             if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
             else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
         } else if (g.out_lo) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
         } else if (g.stats_in) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
         } else if (fast) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
         }
     }
     return launch_status("gemm16");

@@ -2,7 +2,7 @@
 (M = 30 720): plain 16-bit output vs LayerNorm fold (QKV, FFN1); fp32 read-modify-write residual vs split (hi, lo)
 residual with row statistics (out-proj, FFN2).  Modes are interleaved inside one process; medians of R rounds.
 
-    python tools/gemm_mode_bench.py [R]
+    python tools/gemm_mode_bench.py [R] [M] [stagger,stagger,...]     (stagger: bg_tune key 8, see gemm_16bit.hip)
 """
 import os
 import statistics
@@ -12,10 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
-from brepgen_amd import ops
+from brepgen_amd import _lib, ops
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-M = 30720
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 30720
+STAGGERS = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [None]
 dt = torch.bfloat16
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
@@ -57,10 +58,16 @@ for name, N, K, a in (("outproj", 768, 768, a768), ("ffn2", 768, 1024, a1024)):
     cases[name + " split   "] = (lambda a=a, w=w, b=b: ops.linear_ex(a, w, b, split_out=True, res=(hi, lo), want_stats=True), N, K)
     cases[name + " split-ns"] = (lambda a=a, w=w, b=b: ops.linear_ex(a, w, b, split_out=True, res=(hi, lo)), N, K)
 
-res = {k: [] for k in cases}
+res = {(k, st): [] for k in cases for st in STAGGERS}
 for r in range(R):
-    for k, (fn, N, K) in cases.items():
-        res[k].append(timed(fn))
+    for st in STAGGERS:
+        if st is not None:
+            _lib.load().bg_tune_set(8, st)
+        for k, (fn, N, K) in cases.items():
+            res[(k, st)].append(timed(fn))
+print(f"M = {M}")
 for k, (fn, N, K) in cases.items():
-    us = statistics.median(res[k])
-    print(f"{k:20s} {us:7.1f} us  {2.0 * M * N * K / us / 1e6:7.0f} TF   (min {min(res[k]):.1f})")
+    for st in STAGGERS:
+        us = statistics.median(res[(k, st)])
+        tag = "" if st is None else f" stagger {st:4d}"
+        print(f"{k:20s}{tag} {us:7.1f} us  {2.0 * M * N * K / us / 1e6:7.0f} TF   (min {min(res[(k, st)]):.1f})")
