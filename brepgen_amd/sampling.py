@@ -189,14 +189,17 @@ class CascadeSampler:
     every step, sliced by rank (the reference's utils.randn_tensor semantics; what a CPU-driven oracle cascade can
     reproduce bit for bit, at the price of B x S x E x 6 host randoms and a PCIe copy per step on every rank).
 
-    graphs: "auto" (default) -- stages whose eps-evaluation is launch-bound (<= GRAPH_MAX_TOKENS tokens: every stage at
-    the reference's batch 16, the surface stages up to a few hundred samples) replay ONE captured hipGraph per step;
-    True / False force it on / off.  Same kernels in the same order: results are bit-identical either way."""
+    graphs: False (default) -- kernel-by-kernel launches; True -- every stage replays ONE captured hipGraph per step;
+    "auto" -- only stages of <= GRAPH_MAX_TOKENS tokens.  Same kernels in the same order: results are bit-identical
+    either way.  Off by default because it measured flat on the MI355X (whole DeepCAD cascade at the reference's batch
+    16: 2.17 s without, 2.24 s with graphs; profiles/r02/cascade_b16_*.log): at that size a step is ~90 dependent
+    kernels of a few microseconds each and the time is the GPU's own dispatch-to-dispatch latency, not the host's
+    launch rate -- the option is for hosts that ARE launch-bound (slow CPU, many ranks per socket)."""
 
     GRAPH_MAX_TOKENS = 32768
 
     def __init__(self, surfpos, surfz, edgepos, edgez, pndm, ddpm, *, use_cf=False, class_id=0, guidance=0.6,
-                 bbox_threshold=0.08, dist=None, autocast=True, noise_mode="device", graphs="auto"):
+                 bbox_threshold=0.08, dist=None, autocast=True, noise_mode="device", graphs=False):
         if noise_mode not in ("device", "reference"):
             raise ValueError("noise_mode must be 'device' or 'reference'")
         if graphs not in ("auto", True, False):

@@ -236,7 +236,7 @@ class _Program:
 
 
 class _HipVAE(nn.Module):
-    WS_BUDGET = 16 << 30           # bytes of bg_vae_run workspace (activation slots + scratch) per chunk of samples
+    WS_BUDGET = 8 << 30            # bytes of bg_vae_run workspace (activation slots + scratch) per chunk of samples
     IM2COL_BUDGET = 1 << 32        # bytes of im2col scratch per chunk of samples (288 GB of HBM: few, large chunks)
 
     def __init__(self):
@@ -250,9 +250,10 @@ class _HipVAE(nn.Module):
         self._packs = {}
         self._programs = {}
         self._zero = None
+        self._ws = {}                  # (device, stream) -> workspace kept between passes (a fresh multi-GiB hipMalloc costs more than the pass)
 
     def _apply(self, fn, *a, **k):
-        self._packs, self._programs = {}, {}
+        self._packs, self._programs, self._ws = {}, {}, {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
@@ -279,9 +280,13 @@ class _HipVAE(nn.Module):
         need = size(n, chunk)
         if need == 0:
             raise _lib.BrepgenHipError("bg_vae_workspace_bytes: malformed VAE program")
-        ws = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
+        key = (x_cl.device, stream())
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws[key] = None                                     # release the smaller one first
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
         check(lib.bg_vae_run(pg.ops, len(pg.steps), pg.n_slots, h, w, c, ptr(x_cl), n, chunk, ptr(out),
-                             ptr(self._zero_page(x_cl.device)), ptr(ws), need, stream()), "bg_vae_run")
+                             ptr(self._zero_page(x_cl.device)), ptr(ws), ws.numel(), stream()), "bg_vae_run")
         return out
 
     def _use_executor(self):

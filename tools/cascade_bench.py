@@ -19,7 +19,7 @@ from brepgen_amd.sampling import CascadeSampler, decode_latents
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 DATALIKE = len(sys.argv) > 2 and sys.argv[2] == "datalike"
-GRAPHS = {"graphs": True, "nographs": False}.get(sys.argv[3] if len(sys.argv) > 3 else "", "auto")
+GRAPHS = {"graphs": True, "auto": "auto"}.get(sys.argv[3] if len(sys.argv) > 3 else "", False)
 S, E = 30, 30                                                        # eval_config.yaml: deepcad
 torch.manual_seed(0)
 dev = torch.device("cuda")
