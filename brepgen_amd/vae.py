@@ -262,7 +262,7 @@ class _HipVAE(nn.Module):
 
     def _zero_page(self, device):
         if self._zero is None or self._zero.device != device:
-            self._zero = torch.zeros(4096, dtype=torch.uint8, device=device)     # >= 2 * C bytes: one pixel of zeros
+            self._zero = torch.zeros(1 << 16, dtype=torch.uint8, device=device)  # >= 2 * C bytes (one pixel of zeros) for any C <= 32768
         return self._zero
 
     def _run(self, x_cl, out_shape, dt):
