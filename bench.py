@@ -130,17 +130,21 @@ def cpu_baseline(steps=3, warmup=1):
 
 def edge_net_extra(dev, evals=2):
     """Reported BESIDE the headline (never part of `value`): one eps-evaluation of the edge nets at the shapes of
-    BASELINE configs[2] / configs[3] -- where 98 % of the cascade's FLOPs are -- with their own roofline.
+    BASELINE configs[2] / configs[3] / configs[4] (the last one guided: conditional + unconditional rows, fp16) -- where
+    98 % of the cascade's FLOPs are -- with their own roofline.
     Masks per SURVEY 8(d): valid faces per sample ~ U{8..S}, valid edges per valid face ~ U{3..E}."""
     import brepgen_amd as bga
     from brepgen_amd import _lib
     out = []
-    for name, cls, B, S, E, c_tok in (("EdgeZNet cfg3 DeepCAD [256,60,30,18] bf16", bga.EdgeZNet, 256, 60, 30, 4.78e6),
-                                       ("EdgePosNet cfg4 ABC [512,100,40,6] bf16 (one rank's 512 samples)", bga.EdgePosNet, 512, 100, 40, 2.38e6)):
+    for name, cls, B, S, E, c_tok, cf, dt in (
+            ("EdgeZNet cfg3 DeepCAD [256,60,30,18] bf16", bga.EdgeZNet, 256, 60, 30, 4.78e6, False, torch.bfloat16),
+            ("EdgePosNet cfg4 ABC [512,100,40,6] bf16 (one rank's 512 samples)", bga.EdgePosNet, 512, 100, 40, 2.38e6, False, torch.bfloat16),
+            ("EdgeZNet cfg5 Furniture guided [2x256,60,40,18] fp16 (one rank's 256 samples: conditional + unconditional rows "
+             "in one eval)", bga.EdgeZNet, 256, 60, 40, 4.78e6, True, torch.float16)):
         g = torch.Generator().manual_seed(99)
         torch.manual_seed(1)
-        net = cls(False).to(dev).eval()
-        net.compute_dtype = torch.bfloat16
+        net = cls(cf).to(dev).eval()
+        net.compute_dtype = dt
         nf = torch.randint(8, S + 1, (B,), generator=g)
         smask = torch.arange(S)[None] >= nf[:, None]                                     # [B,S] True = padded face
         pos = torch.randn(B, S, 6, generator=g).clamp(-3, 3).to(dev)
@@ -155,9 +159,14 @@ def edge_net_extra(dev, evals=2):
         else:
             ntok = (nf * E).double()
             args = (torch.randn(B, S, E, 6, generator=g).clamp(-3, 3).to(dev), t, pos, sz, smask.to(dev), None)
+        if cf:                                    # sample.py:273-279: inputs repeated, labels [class] * B + [uncond] * B
+            rep = lambda v: v.repeat(2, *([1] * (v.dim() - 1))).contiguous() if torch.is_tensor(v) and v.dim() > 1 else v
+            args = tuple(rep(a) for a in args[:-1]) + (torch.tensor([6] * B + [0] * B, dtype=torch.int64, device=dev).reshape(-1, 1),)
+            ntok = ntok.repeat(2)
+        rows_b = 2 * B if cf else B
         N = S * E
-        f_dense = B * (algorithmic_flops_per_sample_eval(N, c_tok) + S * 2.44e6)
-        f_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), c_tok) for n in ntok)) + B * S * 2.44e6
+        f_dense = rows_b * (algorithmic_flops_per_sample_eval(N, c_tok) + S * 2.44e6)
+        f_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), c_tok) for n in ntok)) + rows_b * S * 2.44e6
         net.profile_hints = (float(ntok.sum()), float((ntok * ntok).sum()))
         row = {"workload": name, "tokens_per_sample": N, "valid_tokens_mean": round(float(ntok.mean()), 1),
                "algorithmic_tflop_per_eval": round(f_dense / 1e12, 2), "executed_tflop_per_eval": round(f_exec / 1e12, 2)}
