@@ -74,7 +74,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;           // 32x32 MFMA tiles per wave
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    constexpr int EPI_BYTES = BM * BN * 4;
+    // epilogue patch: a wave stages its rows 64 at a time (EH = MFMA row tiles per pass), so that the 256 x 256 tile's
+    // patches (8 waves x 16 KiB) fit where the ring was
+    constexpr int EH = TM > 2 ? 2 : TM;
+    constexpr int EPI_BYTES = NW * EH * 32 * (BN / WN) * 4;
     constexpr int LDS_BYTES = (STAGES * STAGE_BYTES > EPI_BYTES) ? STAGES * STAGE_BYTES : EPI_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces must divide evenly over the waves");
@@ -214,20 +217,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     for (; kt < KT; ++kt) ktile(kt, std::false_type{});
     __syncthreads();                                              // all fragment reads done: LDS is free
 
-    // ---- epilogue: accumulators -> wave-private LDS patch -> coalesced rows ----
+    // ---- epilogue: accumulators -> wave-private LDS patch -> coalesced rows, EH x 32 rows per pass ----
     constexpr int PW = TN * 32;                                   // patch width (floats)
-    float* patch = reinterpret_cast<float*>(lds) + wave * (TM * 32 * PW);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D layout of the 32x32 MFMA
-                patch[pr * PW + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
-    __syncthreads();
-
+    float* patch = reinterpret_cast<float*>(lds) + wave * (EH * 32 * PW);
     constexpr int LPR = PW / 4;                                   // lanes per patch row (float4 each)
     constexpr int RPI = 64 / LPR;                                 // rows per iteration
     static_assert(PW == 64, "the row-statistics / LayerNorm-fold code assumes one 64-column group per wave");
@@ -239,10 +231,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     if (g.bias) bias = *reinterpret_cast<const float4*>(g.bias + gcol);
     if (g.stats_in) csum = *reinterpret_cast<const float4*>(g.colsum + gcol);
     const int nparts_in = g.K / G_BK;
+#pragma unroll
+    for (int eh = 0; eh < TM / EH; ++eh) {
+    if (eh > 0) {                                                 // the patch is wave-private: a wave-level fence is enough
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < EH; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // C/D layout of the 32x32 MFMA
+                patch[pr * PW + j * 32 + (lane & 31)] = acc[eh * EH + i][j][r];
+            }
+    if (TM == EH) {                                               // one pass (every shipped instantiation)
+        __syncthreads();
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll 4
-    for (int it = 0; it < TM * 32 / RPI; ++it) {
+    for (int it = 0; it < EH * 32 / RPI; ++it) {
         const int pr = it * RPI + rr;
-        const int grow = m0 + wm * (TM * 32) + pr;
+        const int grow = m0 + wm * (TM * 32) + eh * (EH * 32) + pr;
         const bool row_ok = grow < Mv;
         const int crow = row_ok ? grow : Mv - 1;
         const int prow = g.row_map ? g.row_map[crow] : crow;      // index in the padded token layout (compacted batches)
@@ -313,6 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
                 else reinterpret_cast<float*>(g.out)[(size_t)orow * g.ldc + col] = o;
             }
         }
+    }
     }
 }
 
@@ -822,6 +836,8 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
     } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g);
+    } else if (variant == 6 && g.N_pad % 256 == 0) {              // 256x256, 8 waves (128x64 per wave), 2-stage ring
+        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 256, 2, 4, 2>), dim3(m256 * (g.N_pad / 256)), dim3(512), 0, s, g);
     } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g);
     } else {
