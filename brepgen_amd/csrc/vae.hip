@@ -1,7 +1,10 @@
-// Kernels of the surface / edge VAE decoders (network.py:786-858, 948-1040 + the diffusers==0.27 decoder blocks).
+// Elementwise / gather kernels of the surface / edge VAEs (network.py:690-1040 + the diffusers==0.27 blocks).
 //
-// Layout: channels-last activations, fp32: 2-D [F, H, W, C], 1-D [G, L, C] (== 2-D with H = 1).  Every convolution
-// becomes  im2col (this file) -> MFMA GEMM (gemm_bf16.hip / gemm_f32.hip, bias + residual fused in its epilogue):
+// Layout: channels-last activations, fp32: 2-D [F, H, W, C], 1-D [G, L, C] (== 2-D with H = 1).  A convolution is
+//   16-bit modes, 3x3 / k5, stride 1:  norm_act_kernel (GroupNorm + activation + cast, 1x1 window) -> implicit GEMM
+//                                      (gemm_16bit.hip, CONV instantiation: the GEMM's loader walks the window)
+//   everything else:                   im2col_kernel over the window -> MFMA GEMM (gemm_16bit.hip / gemm_f32.hip)
+// with bias + residual fused in the GEMM epilogue either way:
 //   * the GroupNorm + SiLU / GELU that precedes each conv in ResnetBlock2D / ResConvBlock is applied INSIDE the
 //     im2col gather (per-(sample, group) mean / rstd from gn_stats_kernel), so the normalised tensor never exists;
 //   * the nearest-neighbour x2 up-sampling of Upsample2D is folded into the gather as well (source index >> 1);

@@ -268,9 +268,11 @@ int bg_pndm_step(const float* eps_c, const float* eps_u, float guidance_w, const
                  const float* hist2, float c_h0, float c_h1, float c_h2, float sample_coeff,
                  float eps_coeff, float* out, size_t n, bg_stream_t stream);
 
-/* ---- VAE decoders (AutoencoderKLFastDecode / AutoencoderKL1DFastDecode, network.py:786-858, 948-1040; blocks from
- * diffusers==0.27).  Channels-last fp32 activations [S, H, W, C] (1-D: H = 1).  A convolution is bg_im2col followed
- * by bg_gemm_bias_act_fwd on weights reshaped to [C_out, kh*kw*C_in]. ------------------------------------------ */
+/* ---- VAE steps (AutoencoderKLFastDecode / AutoencoderKL1DFastDecode / ...FastEncode, network.py:690-1040; blocks from
+ * diffusers==0.27).  Channels-last fp32 activations [S, H, W, C] (1-D: H = 1).  A convolution is either bg_im2col with a
+ * 1x1 window (GroupNorm + activation + cast) followed by the implicit GEMM bg_conv_gemm_fwd, or bg_im2col over the whole
+ * window followed by bg_gemm_bias_act_fwd, on weights reshaped to [C_out, kh*kw*C_in]; bg_vae_run (below) strings a whole
+ * pass together. ------------------------------------------------------------------------------------------------- */
 
 /* nn.GroupNorm statistics: stats[s, g] = (mean, 1/sqrt(var + eps)) over the P positions x C/G channels of group g. */
 int bg_groupnorm_stats(const float* x, float* stats /*[S,G,2]*/, int S, int P, int C, int G, float eps,
