@@ -18,8 +18,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
     }
 }
 
-// u32 -> uniform in (0, 1): the top 24 bits, centred (never 0, never 1; exact in fp32)
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// u32 -> uniform in (0, 1): the top 23 bits, centred.  k + 0.5 with k < 2^23 is exactly representable in fp32 (24
+// significant bits), so the 2^23 grid points are equally spaced, none is 0 and none is 1.
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 template <bool RAW>
 __global__ __launch_bounds__(256) void philox_randn_kernel(float* __restrict__ out, long long n_samples, int per,

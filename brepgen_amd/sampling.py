@@ -43,6 +43,19 @@ def sharded_randn(shape, generator, rank, world, device):
     return full[lo:hi].to(device)
 
 
+def noise_key(generator=None):
+    """64-bit key of the device-side ancestral noise of ONE sample() call.
+
+    Derived from the generator's current STATE (the global CPU generator when none is given), not from its initial
+    seed: the state has advanced by the initial-latent draws of every earlier call, so successive calls that share one
+    generator get independent noise (upstream draws fresh noise from an advancing RNG, sample.py:153), while two
+    generators seeded alike still reproduce each other.  Nothing is consumed -- the four initial-latent draws keep the
+    reference's seed semantics -- and every rank holds the same state, so the key is rank-independent."""
+    import hashlib
+    st = (generator if generator is not None else torch.default_generator).get_state()
+    return int.from_bytes(hashlib.blake2b(st.cpu().numpy().tobytes(), digest_size=8).digest(), "little")
+
+
 def device_randn(shape, seed, draw_id, first_sample, device):
     """N(0,1) of `shape` (= this rank's rows) drawn on the device; row b is global sample first_sample + b."""
     out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
@@ -279,7 +292,7 @@ class CascadeSampler:
         b = hi - lo
         finish = (lambda o: gather_latents(o, self.dist, batch_size=batch_size)) if gather else (lambda o: o)
         # every rank consumes the CPU generator identically (4 whole-batch draws), whether or not it owns samples
-        seed = generator.initial_seed() if generator is not None else torch.initial_seed()
+        seed = noise_key(generator)
         draw = [0]
 
         def ancestral(shape, t):

@@ -46,7 +46,7 @@ def raw_bits(n_samples, per_sample, seed, draw_id, first_sample=0):
 def randn(n_samples, per_sample, seed, draw_id, first_sample=0):
     """float32 [n_samples, per_sample]: Box-Muller on the four words of each counter (fp32 arithmetic like the kernel)."""
     bits = philox4x32_10(counters(n_samples, per_sample, draw_id, first_sample), (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
-    u = ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    u = ((bits >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)   # 23 bits + 1/2: exact in fp32
     r0 = np.sqrt(np.float32(-2.0) * np.log(u[..., 0]))
     r1 = np.sqrt(np.float32(-2.0) * np.log(u[..., 2]))
     a0 = np.float32(6.28318530717958647692) * u[..., 1]

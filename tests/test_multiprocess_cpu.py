@@ -102,3 +102,24 @@ def test_dedup_edges_marks_duplicates_and_padded_faces():
     m = dedup_edges(e, smask, 0.08)
     assert m[0, 0].tolist() == [False, True, False, True]
     assert m[0, 1].all()
+
+
+def test_noise_key_advances_with_the_generator_and_consumes_nothing():
+    """the device-side ancestral noise must differ between successive sample() calls that share one
+    generator (pipeline.main --batches N), reproduce for equally seeded generators, and leave the generator untouched
+    (the initial latents keep the reference's seed semantics)."""
+    from brepgen_amd.sampling import noise_key
+    g1, g2 = torch.Generator().manual_seed(77), torch.Generator().manual_seed(77)
+    k1 = noise_key(g1)
+    assert k1 == noise_key(g2) and 0 <= k1 < 2 ** 64
+    st = g1.get_state().clone()
+    assert torch.equal(st, g1.get_state()) and noise_key(g1) == k1          # nothing consumed, deterministic
+    a = sharded_randn((4, 3), g1, 0, 1, "cpu")                            # what one sample() call draws
+    k1b = noise_key(g1)
+    assert k1b != k1                                                       # the next call gets fresh noise
+    assert torch.equal(a, sharded_randn((4, 3), g2, 0, 1, "cpu")) and noise_key(g2) == k1b
+    assert noise_key(torch.Generator().manual_seed(78)) != k1
+    torch.manual_seed(5)                                                   # generator=None -> the global CPU generator
+    ka = noise_key(None)
+    torch.randn(3)
+    assert noise_key(None) != ka

@@ -27,3 +27,14 @@ def test_moments():
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01
     assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1
     assert np.isfinite(z).all()
+
+
+def test_uniform_grid_is_exact_in_fp32():
+    """u01 = (top 23 bits + 1/2) * 2^-23 (csrc/rng.hip): every grid point is exactly representable, strictly inside (0, 1)
+    and equally spaced -- the 24-bit variant rounds k + 1/2 to even above 2^23 and reaches 1.0."""
+    k = np.array([0, 1, 2 ** 22, 2 ** 23 - 2, 2 ** 23 - 1], dtype=np.uint32)
+    u = (k.astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 8388608.0)
+    exact = (k.astype(np.float64) + 0.5) / 8388608.0
+    assert np.array_equal(u.astype(np.float64), exact) and u.min() > 0 and u.max() < 1
+    bad = (np.float32(2 ** 24 - 1) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+    assert bad == np.float32(1.0)                                          # what the old formula did

@@ -80,3 +80,18 @@ for M in MS:
         a, b = statistics.median(res[(k, 0)]), statistics.median(res[(k, VAR)])
         print(f"  {k:18s} shipped {a:8.1f} us {2.0 * M * N * K / a / 1e6:6.0f} TF | variant {VAR} {b:8.1f} us {2.0 * M * N * K / b / 1e6:6.0f} TF  ({a / b:.2f}x)")
 lib.bg_tune_set(0, 0)
+# ---- K-loop quality away from the per-tile overhead: square problems (the guide's 8-phase template reaches ~1330 / ~1470 TF
+# at 4096^3 / 8192^3 on uniform random operands) ----
+if os.environ.get("BG_SQUARE", "1") == "1":
+    for S in (4096, 8192):
+        a = (rn(S, S) * 0.5).to(dt).to(dev)
+        w = (rn(S, S) * 0.04).to(dt).to(dev)
+        b = rn(S).to(dev)
+        fn = lambda: ops.linear(a, w, b, out_dtype=dt)
+        line = f"square {S}^3 plain:"
+        for v in (0, 6, VAR):
+            lib.bg_tune_set(0, v)
+            us = statistics.median(timed(fn, 10) for _ in range(3))
+            line += f"  variant {v}: {us:8.1f} us {2.0 * S * S * S / us / 1e6:6.0f} TF"
+        print(line)
+    lib.bg_tune_set(0, 0)
