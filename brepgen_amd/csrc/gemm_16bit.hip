@@ -29,39 +29,14 @@
 // The exploration behind this shape (3-stage rings, 256-row tiles, register epilogue, loader/consumer wave
 // specialisation, ablations) is summarised in DESIGN.md section 4 with the logs under profiles/r01/; those kernel
 // variants live in the git history (commit "Persistent 128x128 GEMM ...").
-#include "bg_common.h"
-#include <type_traits>
+#include "gemm16.h"
 
 namespace bg {
-
-constexpr int G_BK = 64;            // 16-bit elements per K-step = 128 bytes per tile row
-
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-
-template <bool F16> struct Elem;
-template <> struct Elem<false> {
-    using T = __bf16; using V8 = bf16x8; using V4 = bf16x4;
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ V4 pack4(float a, float b, float c, float d) { return to_bf16x4(a, b, c, d); }
-};
-template <> struct Elem<true> {
-    using T = _Float16; using V8 = f16x8; using V4 = f16x4;
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ V4 pack4(float a, float b, float c, float d) {
-        V4 r; r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d; return r;
-    }
-};
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base) {
     // dst = wave-uniform base + lane * 16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // LDS-DMA from inline asm (1 KiB per wave-instruction: lane l's 16 bytes land at lds_wave_base + 16 l).  Unlike the builtin,
@@ -495,8 +470,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   P_GENERAL  fp32 or 16-bit output with fp32 addends (add / add2)     -- fp32 residual stream, embeds, VAE residuals
 //   P_SPLIT    split (hi, lo) output, addend = split residual or fp32 broadcast rows, optional row statistics
 //                                                                       -- out-proj / FFN2 / token embeds of the denoisers
-enum { P_PLAIN16 = 0, P_FOLD16 = 1, P_GENERAL = 2, P_SPLIT = 3 };
-constexpr int FOLD_PARTS = 12;      // the persistent kernel's LayerNorm fold is compiled for K = 768 (LN width of the denoisers)
 
 template <bool F16, int MODE, bool INSTR, bool CONV = false>      // CONV: the A operand is gathered from a conv window (implicit GEMM)
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg,
@@ -976,6 +949,13 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in || variant != 0)) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;
+    }
+    // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs once a launch has enough tiles to fill
+    // the chip (bg_tune key 10: 0 = by tile count, 1 = wherever eligible, 2 = never; key 11 overrides the tile threshold)
+    if (variant == 0 && g_tune[TUNE_P256_MODE] != 2 && p256_eligible(g)) {
+        const int t256 = m256 * (g.N_pad / 256);
+        const int thr = g_tune[TUNE_P256_MIN_TILES] > 0 ? g_tune[TUNE_P256_MIN_TILES] : 192;
+        if (g_tune[TUNE_P256_MODE] == 1 || t256 >= thr) return launch_p256<F16>(g, s);
     }
     if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);

@@ -1,0 +1,438 @@
+// 16-bit MFMA GEMM, 256 x 256 x 64 tile, persistent, 8-phase K loop -- the MFMA-bound Linears of the denoisers (QKV and FFN1 with
+// the LayerNorm fold, network.py:1076-1078 -> torch/nn/modules/transformer.py) at batch sizes that fill the chip.
+//
+//   out[m,n] = act(sum_k a[m,k] * w[n,k] + bias[n])          (P_PLAIN16)
+//   out[m,n] = act(rstd_m * acc - mean_m rstd_m colsum[n] + bias[n])   (P_FOLD16: a = raw residual rows, see gemm_16bit.hip)
+//
+// Why a second kernel next to the 128 x 128 persistent one (gemm_16bit.hip): that kernel's K loop needs 512 B of LDS-DMA per MFMA and
+// tops out at ~0.3 of the MFMA peak; a 256 x 256 tile needs 256 B per MFMA, and the 8-phase schedule of the CDNA programming guide
+// (section 5, "the 256^2 8-phase template") keeps the matrix pipe of every SIMD fed by two waves that alternate between an MFMA
+// segment and a fragment-read + DMA-issue segment.  Measured on MI355X (profiles/r03/gemm_variant7_8phase_generic.log): the loop
+// alone runs 1185 / 1294 TF at 4096^3 / 8192^3 against 753 / 868 TF for the 128 x 128 kernel -- but as a one-tile-per-workgroup
+// kernel with the generic epilogue it LOSES at K = 768 (12 K-steps per tile: pipeline fill + a 128 KiB epilogue per tile with
+// nothing to hide behind).  This kernel removes that per-tile cost:
+//   * persistent: one 8-wave workgroup per CU walks an XCD-aware tile list; the LDS-DMA stream never stops at a tile seam (the last
+//     two K-steps of a tile already stage K-steps 0 and 1 of the next tile: the seam is just a change of base pointers);
+//   * v_mfma_f32_32x32x16 computes the TRANSPOSED product (weights as the A operand): a lane then owns ONE output row and four
+//     consecutive columns per accumulator quad, so the epilogue packs 16-bit pairs without any cross-lane exchange and reads
+//     per-row LayerNorm coefficients from two registers.  The instruction is bit-symmetric in its operands
+//     (tools/mfma_swap_probe.hip, profiles/r03/mfma_swap_probe.log) and the k order is that of every other GEMM kernel here, so
+//     results stay bit-identical to theirs (tests/test_gpu_round3.py);
+//   * epilogue: accumulators -> 16-bit -> a wave-private 4 KiB LDS patch (conflict-free both ways: 16-byte XOR swizzle + a
+//     half swap on odd row octets) -> 16-byte stores of whole 128-byte output lines.  The patch does not alias the ring, no
+//     workgroup barrier is involved.
+//
+// K loop (validated as `variant 7` of the generic kernel before it moved here).  Tile = 8 waves as 2 (rows) x 4 (columns), 128 x 64
+// per wave = 4 x 2 MFMA tiles.  Two 64 KiB buffers (K-steps t, t+1), each four 16 KiB half-tiles: A rows 0-127 / 128-255, W rows
+// 0-127 / 128-255; every wave moves two 1 KiB pieces of a half-tile.  Waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD
+// one wave is in its 8-MFMA segment while the other reads fragments and issues DMA.  Per iteration (two K-steps), phase p =
+// [reads + one half-tile of DMA] barrier [8 MFMAs] barrier:
+//   p   reads (buffer)        LDS-DMA issued (2 per wave)       wait            MFMAs (quadrant of the wave's 128 x 64)
+//   1   W q0, A q0   (0)      buffer 1, W rows   0-127 (t+1)                    Q00
+//   2   A q1         (0)      buffer 1, W rows 128-255 (t+1)                    Q10
+//   3   W q1         (0)      buffer 0, A rows   0-127 (t+2)                    Q11
+//   4   --                    buffer 0, A rows 128-255 (t+2)    vmcnt(4)        Q01   -> buffer 1 (t+1) landed
+//   5   W q0, A q0   (1)      buffer 0, W rows   0-127 (t+2)                    Q00
+//   6   A q1         (1)      buffer 0, W rows 128-255 (t+2)                    Q10
+//   7   W q1         (1)      buffer 1, A rows   0-127 (t+3)                    Q11
+//   8   --                    buffer 1, A rows 128-255 (t+3)    vmcnt(4)        Q01   -> buffer 0 (t+2) landed
+// (t+2, t+3 = K-steps 0, 1 of the NEXT tile in the last iteration of a tile.)  Write-after-read: A rows 0-127 are read by waves
+// 0-3 only, A rows 128-255 by waves 4-7 one barrier later, W by everybody; each half is re-staged >= 2 barriers after the
+// lgkmcnt(0) that retired its last read.  Read-after-write: the counted vmcnt sits before the first barrier of phases 4 / 8, the
+// first read of that buffer two (waves 0-3) or three (waves 4-7) barriers later.  vmcnt also counts the epilogue's stores: they
+// are older than the DMA a later vmcnt(4) leaves in flight, so a count can only wait for more than it needs, never for less.
+#include "gemm16.h"
+
+namespace bg {
+
+constexpr int P256_BUF = 65536, P256_HALF = 16384, P256_RING = 2 * P256_BUF, P256_PATCH = 4096;
+
+// A value the compiler must treat as unknown at this point: everything derived from it is (re)computed here instead of being kept
+// in a register across the K loop -- the loop runs at the 256-VGPR limit, and a spilled value costs more than its register: hipcc
+// follows every scratch reload with s_waitcnt vmcnt(0), which drains the LDS-DMA pipeline.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+template <bool F16, int MODE, bool NARROW>
+__global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_epilogue, int stagger_units, int nt_stores) {
+    constexpr bool FOLD = MODE == P_FOLD16;
+    static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16, "16-bit output epilogues only");
+    static_assert(NARROW || !FOLD, "the LayerNorm-fold epilogue is written for 32-column passes");
+    using E = Elem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[P256_RING + 8 * P256_PATCH];     // 160 KiB: one workgroup per CU
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
+    const int nt_n = g.N_pad >> 8;
+    const int T_all = ((Mv + 255) >> 8) * nt_n;
+    const int G = gridDim.x;
+    // XCD-aware walk: workgroup b (on XCD b % 8) owns tiles first, first + G, ... of the row-major tile list, `first` being
+    // consecutive for the workgroups of one XCD -- the ~32 tiles an XCD runs at a time cover 3-4 row panels x all column tiles, so
+    // an A panel is fetched into that L2 once and the W tiles stay resident.
+    int L = xcd_remap(blockIdx.x, G);
+    if (L >= T_all) return;                                       // uniform per workgroup, before any barrier
+    // Start stagger.  Launched together with equal tiles, all 256 workgroups would reach their epilogues at the same moment, every
+    // round: 32 MB of output hit the fabric at once (measured: ~6.5 us per round at ~5 TB/s) while the memory system idles during
+    // the K loops.  Workgroup b therefore starts c(b) x stagger_units x 64 cycles late, c in 0..31, once per launch: the epilogues
+    // of a round then arrive spread over about one burst length and each drains at its own CU's rate (the host sets
+    // stagger_units = 0 for launches of a single round, where the delay would cost more than it saves).
+    if (stagger_units > 0) {
+        const int c = ((int)(blockIdx.x >> 3) + 4 * (int)(blockIdx.x & 7)) & 31;
+        for (int n = c * stagger_units; n > 0; --n) __builtin_amdgcn_s_sleep(1);
+    }
+
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.a);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.w);
+    const unsigned lda_b = (unsigned)g.lda * 2u, ldw_b = (unsigned)g.K * 2u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds);
+    const unsigned patch_lds = lds0 + (unsigned)(P256_RING + wave * P256_PATCH);
+    unsigned char* patch = lds + P256_RING + wave * P256_PATCH;
+    const bool has_bias = g.bias != nullptr;
+
+    // ---- LDS-DMA: wave w moves pieces w and w + 8 (8 rows x 128 B each) of every 128-row half-tile ----
+    // Source = wave-uniform base (SGPR pair: tile origin + k offset + half offset) + 32-bit per-lane byte offset; the 16-byte chunk
+    // index is XOR-swizzled on the source side (the DMA writes lane-linear), the fragment reads apply the same involution.
+    auto dma = [&](unsigned dst, const unsigned char* src, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    };
+    auto stage = [&](int buf, int h4, const unsigned char* src, const unsigned (&off)[2]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            dma(lds0 + (unsigned)(buf * P256_BUF + h4 * P256_HALF + (wave + 8 * r) * 1024), src, off[r]);
+    };
+    unsigned hw[2], ha[2][2];                                     // per-lane source offsets: W rows (either half), A rows per half
+    auto piece_row = [&](int ln, int r) { return (wave + 8 * r) * 8 + (ln >> 3); };            // row inside the half-tile
+    auto piece_chunk = [&](int ln, int r) { return (unsigned)(((ln & 7) ^ ((piece_row(ln, r) >> 1) & 7)) * 16); };
+    auto a_offsets = [&](int m0t) {                               // (re)computed at every tile seam from an opaque lane id
+        const int ln = opaque(threadIdx.x & 63);
+        const int last = Mv - 1 - m0t;                            // rows >= Mv are clamped (never stored)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int row = hh * 128 + piece_row(ln, r);
+                row = row < last ? row : last;
+                ha[hh][r] = (unsigned)row * lda_b + piece_chunk(ln, r);
+            }
+    };
+    {
+        const int ln = threadIdx.x & 63;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) hw[r] = (unsigned)piece_row(ln, r) * ldw_b + piece_chunk(ln, r);
+    }
+    const unsigned w_half = 128u * ldw_b;                         // W rows 128-255: the same lane offsets on a shifted base
+
+    // Epilogue operands wait in the wave's patch while the K loop runs (no registers).  Two epilogue shapes:
+    //   * !NARROW (plain output): passes of 32 rows x 64 columns fill the 4 KiB patch; the tile's bias (1 KiB = 256 columns, one
+    //     LDS-DMA piece) sits in [0, 1K) between epilogues and is read into registers before the first pass overwrites it;
+    //   * NARROW (LayerNorm fold, or plain as an A/B): passes of 32 rows x 32 columns use [0, 2K); [2K, 2K+256) holds the wave's 64
+    //     bias values, [2K+256, 2K+512) its 64 column sums, [2.5K, 3.5K) the (rstd, -mean rstd) pairs of the wave's 128 rows -- read
+    //     per pass, so the epilogue never holds more than one column tile's constants in registers.
+    // The column vectors are DMA'd at the END of the previous tile's epilogue (here: in the prologue): an L2 round trip per tile
+    // would otherwise sit in front of every epilogue, and a plain load there would make hipcc wait for vmcnt(0), i.e. for the
+    // next tile's DMA as well.
+    auto stage_cols = [&](int n0c) {
+        const int ln = opaque(threadIdx.x & 63);
+        if (NARROW) {
+            if (ln < 16) {                                        // 16 lanes x 16 B = this wave's 64 columns
+                if (has_bias) dma(patch_lds + 2048u, reinterpret_cast<const unsigned char*>(g.bias + n0c + wn * 64), (unsigned)ln * 16u);
+                if (FOLD) dma(patch_lds + 2304u, reinterpret_cast<const unsigned char*>(g.colsum + n0c + wn * 64), (unsigned)ln * 16u);
+            }
+        } else if (has_bias) {
+            dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), (unsigned)ln * 16u);
+        }
+    };
+    // LayerNorm fold: (rstd, -mean * rstd) of the wave's 128 rows of a tile.  The lower half wave works out row tiles 0, 1, the
+    // upper half 2, 3 (row tile i -> row m0 + wm*128 + 32 i + l31), each from the row's 12 partial (sum, sum of squares) pairs in
+    // the association order every kernel uses (tree16).  Load and use are separate calls so that the epilogue can put its own
+    // work in between.
+    struct RowStats { f32x16 lo; f32x8 hi; };                     // 12 (sum, sum of squares) pairs as SSA values (never an array in
+                                                                  // memory: hipcc left a float2[12] on the stack, one waited load at a time)
+    auto stats_load = [&](int m0t, int ii) -> RowStats {         // this half wave's row tile 2 h + ii
+        const int ln = opaque(threadIdx.x & 63);
+        int grow = m0t + wm * 128 + (2 * (ln >> 5) + ii) * 32 + (ln & 31);
+        grow = grow < Mv ? grow : Mv - 1;
+        const float2* sp = reinterpret_cast<const float2*>(g.stats_in) + grow;                 // part-major: [K/64][M] pairs
+        RowStats r;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { const float2 v = sp[(size_t)p * g.M]; r.lo[2 * p] = v.x; r.lo[2 * p + 1] = v.y; }
+#pragma unroll
+        for (int p = 8; p < FOLD_PARTS; ++p) { const float2 v = sp[(size_t)p * g.M]; r.hi[2 * (p - 8)] = v.x; r.hi[2 * (p - 8) + 1] = v.y; }
+        return r;
+    };
+    auto stats_coeffs = [&](RowStats r, int ii) {
+        const int ln = opaque(threadIdx.x & 63);
+        float ps[16], pq[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            ps[p] = p < 8 ? r.lo[2 * (p & 7)] : (p < FOLD_PARTS ? r.hi[2 * (p & 3)] : 0.f);
+            pq[p] = p < 8 ? r.lo[2 * (p & 7) + 1] : (p < FOLD_PARTS ? r.hi[2 * (p & 3) + 1] : 0.f);
+        }
+        reinterpret_cast<float2*>(patch + 2560)[(2 * (ln >> 5) + ii) * 32 + (ln & 31)] =
+            ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+    };
+
+    // ---- fragment read addresses inside a buffer (A rows first, W rows at +32 KiB) ----
+    unsigned a_rd, b_rd, xk[4];
+    {
+        const int ln = threadIdx.x & 63, l31 = ln & 31, hq = ln >> 5, sw = (l31 >> 1) & 7;
+        a_rd = (unsigned)(wm * 128 + l31) * 128u;                 // + i * 4096
+        b_rd = 32768u + (unsigned)(wn * 64 + l31) * 128u;         // + j * 4096
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xk[ks] = (unsigned)(((ks * 2 + hq) ^ sw) << 4);
+    }
+    f32x16 acc[4][2];
+    V8 fa[2][2][4], fb[4];                                        // A sub-tiles q = 0, 1 (2 row tiles x 4 k-slices), one W sub-tile
+    auto read_a = [&](const unsigned char* st, int qm) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fa[qm][i][ks] = *reinterpret_cast<const V8*>(st + a_rd + (2 * qm + i) * 4096 + xk[ks]);
+    };
+    auto read_b = [&](const unsigned char* st, int qn) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const V8*>(st + b_rd + qn * 4096 + xk[ks]);
+    };
+    auto quadrant = [&](int qm, int qn) {                         // 8 MFMAs: rows qm*64..+63 x columns qn*32..+31 of the wave's block
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)                           // transposed product: lane = output row, registers = columns
+                acc[2 * qm + i][qn] = E::mfma(fb[ks], fa[qm][i][ks], acc[2 * qm + i][qn]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar = [&]() {                                            // raw barrier; nothing -- at IR or machine level -- moves across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+
+    const int KT = g.K / G_BK;                                    // even, >= 2 (launcher)
+    const unsigned char* b0 = lds;
+    const unsigned char* b1 = lds + P256_BUF;
+
+    int m0 = (L / nt_n) << 8, n0 = (L % nt_n) << 8;
+    const unsigned char* a_cur = Ab + (size_t)m0 * lda_b;
+    const unsigned char* w_cur = Wb + (size_t)n0 * ldw_b;
+    a_offsets(m0);
+    if (FOLD) { stats_coeffs(stats_load(m0, 0), 0); stats_coeffs(stats_load(m0, 1), 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stage_cols(n0);
+
+    // ---- prologue: buffer 0 complete, the two A halves of buffer 1 in flight (as if issued in phases 7, 8) ----
+    stage(0, 0, a_cur, ha[0]); stage(0, 1, a_cur, ha[1]); stage(0, 2, w_cur, hw); stage(0, 3, w_cur + w_half, hw);
+    stage(1, 0, a_cur + 2 * G_BK, ha[0]); stage(1, 1, a_cur + 2 * G_BK, ha[1]);
+    wait_vmcnt<4>();
+    bar();
+    if (wm == 1) bar();                                           // waves 4-7 run one barrier behind
+
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // the next tile of this workgroup (its first two K-steps are staged by the last iteration below)
+        const int Ln = L + G;
+        const bool has_next = Ln < T_all;
+        const int m0n = (Ln / nt_n) << 8, n0n = (Ln % nt_n) << 8;
+        const unsigned char* a_nxt = Ab + (size_t)m0n * lda_b;
+        const unsigned char* w_nxt = Wb + (size_t)n0n * ldw_b;
+
+        // one iteration = K-steps t (buffer 0) and t + 1 (buffer 1).  w1: K-step t + 1 of W; (a2, w2): where K-step t + 2 comes
+        // from, a3: K-step t + 3's A rows (`ha` holds the lane offsets of whichever tile a2 / a3 belong to); more = those exist.
+        auto iteration = [&](const unsigned char* w1, bool more, const unsigned char* a2, const unsigned char* w2,
+                             const unsigned char* a3) {
+            // phase 1
+            read_b(b0, 0); __builtin_amdgcn_sched_barrier(0); read_a(b0, 0);
+            stage(1, 2, w1, hw);
+            bar(); quadrant(0, 0); bar();
+            // phase 2
+            read_a(b0, 1);
+            stage(1, 3, w1 + w_half, hw);
+            bar(); quadrant(1, 0); bar();
+            // phase 3
+            read_b(b0, 1);
+            if (more) stage(0, 0, a2, ha[0]);
+            bar(); quadrant(1, 1); bar();
+            // phase 4
+            if (more) { stage(0, 1, a2, ha[1]); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+            bar(); quadrant(0, 1); bar();
+            // phase 5
+            read_b(b1, 0); __builtin_amdgcn_sched_barrier(0); read_a(b1, 0);
+            if (more) stage(0, 2, w2, hw);
+            bar(); quadrant(0, 0); bar();
+            // phase 6
+            read_a(b1, 1);
+            if (more) stage(0, 3, w2 + w_half, hw);
+            bar(); quadrant(1, 0); bar();
+            // phase 7
+            read_b(b1, 1);
+            if (more) stage(1, 0, a3, ha[0]);
+            bar(); quadrant(1, 1); bar();
+            // phase 8
+            if (more) { stage(1, 1, a3, ha[1]); wait_vmcnt<4>(); }
+            bar(); quadrant(0, 1); bar();
+        };
+        for (int t = 0; t + 2 < KT; t += 2) {
+            const unsigned kb = (unsigned)t * (2 * G_BK);         // byte offset of K-step t inside a row
+            iteration(w_cur + kb + 2 * G_BK, true, a_cur + kb + 4 * G_BK, w_cur + kb + 4 * G_BK, a_cur + kb + 6 * G_BK);
+        }
+        if (has_next) a_offsets(m0n);                             // the last iteration stages A rows of the next tile only
+        iteration(w_cur + (unsigned)(KT - 1) * (2 * G_BK), has_next, a_nxt, w_nxt, a_nxt + 2 * G_BK);
+
+        // ---------------- epilogue ----------------
+        if (align_epilogue && wm == 0) bar();                     // both wave groups run their epilogues together (see launcher)
+        {
+            const int ln = opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
+            const int rbase = m0 + wm * 128, cbase = n0 + wn * 64;
+            T* out = reinterpret_cast<T*>(g.out);
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            auto store16 = [&](int grow, int col, uint4 v) {
+                if (grow < Mv) {
+                    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
+                    const u32x4 vv = {v.x, v.y, v.z, v.w};
+                    if (nt_stores) __builtin_nontemporal_store(vv, dst);
+                    else *dst = vv;
+                }
+            };
+            // one accumulator quad (row l31 of row tile i, columns j*32 + 8 q + 4 hq .. +3) -> 4 x 16 bit
+            auto quad = [&](int i, int j, int q, float4 b, float4 c, float2 cf) -> uint2 {
+                const float b4[4] = {b.x, b.y, b.z, b.w}, c4[4] = {c.x, c.y, c.z, c.w};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[i][j][4 * q + e];
+                    v[e] = FOLD ? ln_fold_apply(x, cf.x, cf.y, c4[e], b4[e]) : x + b4[e];
+                    if (g.act == BG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                union { V4 v; uint2 u; } pk;
+                pk.v = E::pack4(v[0], v[1], v[2], v[3]);
+                return pk.u;
+            };
+            const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!NARROW) {
+                // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias
+                float4 bz[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bz[j][q] = has_bias ? *reinterpret_cast<const float4*>(patch + (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u) : zero4;
+                // patch rows of 128 B; 16-byte chunk (j*4 + q) XOR-swizzled by the row; rows 8-15 / 24-31 swap the two 8-byte
+                // halves, so the 16 lanes of a ds_write_b64 service group hit 32 distinct banks
+                const unsigned wr_base = (unsigned)l31 * 128u + (unsigned)((hq ^ ((l31 >> 3) & 1)) * 8);
+                const unsigned rd_off = (unsigned)(ln >> 3) * 128u + (unsigned)(((ln & 7) ^ (ln >> 3)) * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<uint2*>(patch + wr_base + (unsigned)(((j * 4 + q) ^ (l31 & 7)) * 16)) =
+                                quad(i, j, q, bz[j][q], zero4, make_float2(1.f, 0.f));
+                    __builtin_amdgcn_wave_barrier();              // LDS executes a wave's accesses in order: no wait needed
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        uint4 v = *reinterpret_cast<const uint4*>(patch + it * 1024 + rd_off);
+                        if (it & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+                        store16(rbase + i * 32 + it * 8 + (ln >> 3), cbase + (ln & 7) * 8, v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                // patch rows of 64 B (32 columns); 16-byte chunk q XOR-swizzled by (row >> 1) & 3: ds_read_b128 conflict-free,
+                // ds_write_b64 2-way (costs nothing at its issue rate)
+                const unsigned wr_base = (unsigned)l31 * 64u + (unsigned)(hq * 8);
+                const unsigned rd_row = (unsigned)(ln >> 2);
+                auto pass = [&](int i, int j) {
+                    float4 b[4], c[4];
+                    float2 cf = make_float2(1.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned off = (unsigned)(j * 32 + 8 * q + 4 * hq) * 4u;
+                        b[q] = has_bias ? *reinterpret_cast<const float4*>(patch + 2048 + off) : zero4;
+                        c[q] = FOLD ? *reinterpret_cast<const float4*>(patch + 2304 + off) : zero4;
+                    }
+                    if (FOLD) cf = reinterpret_cast<const float2*>(patch + 2560)[i * 32 + l31];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<uint2*>(patch + wr_base + (unsigned)((q ^ ((l31 >> 1) & 3)) * 16)) = quad(i, j, q, b[q], c[q], cf);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const unsigned row = it * 16 + rd_row;
+                        const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 64u + (((ln & 3) ^ ((row >> 1) & 3)) * 16));
+                        store16(rbase + i * 32 + (int)row, cbase + j * 32 + (ln & 3) * 8, v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                };
+                // The next tile's row statistics are requested between the passes -- accumulator registers are free by then -- and
+                // turned into coefficients a few passes later: their latency hides behind this epilogue's own work.  The
+                // coefficient slots of row tiles 0, 1 (2, 3) are free once the passes of those row tiles are done.
+                pass(0, 0); pass(0, 1); pass(1, 0); pass(1, 1);
+                // (unconditional: without a next tile the clamped rows are loaded and the results never read)
+                __builtin_amdgcn_sched_barrier(0);
+                const RowStats rs = stats_load(m0n, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                pass(2, 0); pass(2, 1); pass(3, 0); pass(3, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FOLD) { stats_coeffs(rs, 0); stats_coeffs(stats_load(m0n, 1), 1); }
+            }
+            if (has_next) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the patch accesses above are complete
+                stage_cols(n0n);
+            }
+        }
+        if (!has_next) break;
+        if (align_epilogue && wm == 1) bar();                     // restore the one-barrier lag of waves 4-7
+        L = Ln; m0 = m0n; n0 = n0n; a_cur = a_nxt; w_cur = w_nxt;
+    }
+    if (!align_epilogue && wm == 0) bar();                        // pairs with the extra barrier of waves 4-7
+}
+
+bool p256_eligible(const GemmArgs& g) {
+    const bool fold = g.stats_in != nullptr;
+    return g.N_pad % 256 == 0 && g.N == g.N_pad && g.K % (2 * G_BK) == 0 && g.K >= 2 * G_BK && g.ldc % 8 == 0 &&
+           g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.out_lo == nullptr && g.res_hi == nullptr &&
+           g.stats_out == nullptr && g.row_map == nullptr && g.cv_C == 0 &&
+           (!fold || (g.K == FOLD_PARTS * G_BK && g.colsum != nullptr && g.bias != nullptr)) &&
+           (size_t)255 * g.lda * 2 + 128 < 0xffffffffull && (size_t)255 * g.K * 2 + 128 < 0xffffffffull;
+}
+
+template <bool F16>
+int launch_p256(const GemmArgs& g, hipStream_t s) {
+    const int tiles = ((g.M + 255) / 256) * (g.N_pad / 256);
+    const int grid = tiles < 256 ? tiles : 256;
+    const int align = g_tune[TUNE_P256_ALIGN] != 2;               // bg_tune key 9: 2 = wave groups enter the epilogue one barrier apart
+    // start stagger (see the kernel): 32 cohorts x units x 64 cycles; only when a workgroup walks at least two tiles
+    const int units = g_tune[TUNE_P256_STAGGER] > 0 ? g_tune[TUNE_P256_STAGGER] - 1 : 6;
+    const int stg = tiles >= 2 * 256 - 64 ? units : 0;
+    const int nt = g_tune[TUNE_P256_NT];
+    if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else if (g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    return launch_status("gemm16_p256");
+}
+template int launch_p256<false>(const GemmArgs&, hipStream_t);
+template int launch_p256<true>(const GemmArgs&, hipStream_t);
+
+}  // namespace bg

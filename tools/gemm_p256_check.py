@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""The 256 x 256 persistent 8-phase GEMM (csrc/gemm_p256.hip) against the 128 x 128 persistent kernel: bit-equality of the
+plain / LayerNorm-fold epilogues on ragged row counts (bf16 and fp16), then interleaved timings on the per-layer shapes and on
+square problems.   python tools/gemm_p256_check.py [M ...]      (bg_tune key 10: 1 = force the 256 kernel, 2 = never; key 9:
+1 = both wave groups enter the epilogue together)"""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from brepgen_amd import _lib, ops
+
+MS = [int(v) for v in sys.argv[1:]] or [17280, 30720, 138752]
+lib = _lib.load()
+dev = "cuda"
+g = torch.Generator().manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g)
+
+
+def setv(mode, al, stg, nt, nar):
+    lib.bg_tune_set(10, mode); lib.bg_tune_set(9, al); lib.bg_tune_set(12, stg); lib.bg_tune_set(13, nt); lib.bg_tune_set(14, nar)
+
+
+def build(M, dt):
+    x = rn(M, 768) * 2
+    hi = x.to(dt).to(dev)
+    grp = x.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().to(dev)
+    cases = {}
+    for name, N, K, a in (("qkv", 2304, 768, hi), ("ffn1", 1024, 768, hi)):
+        w, b = (rn(N, K) * 0.04).to(dt).to(dev), rn(N).to(dev)
+        cs = w.float().sum(1).contiguous()
+        act = 1 if name == "ffn1" else 0
+        cases[name + " plain"] = (lambda a=a, w=w, b=b, act=act: ops.linear(a, w, b, out_dtype=dt, act=act), N, K)
+        cases[name + " nobias"] = (lambda a=a, w=w: ops.linear(a, w, None, out_dtype=dt), N, K)
+        cases[name + " fold"] = (lambda a=a, w=w, b=b, act=act, cs=cs: ops.linear_ex(a, w, b, act=act, stats_in=stats, colsum=cs)["out"], N, K)
+    return cases
+
+
+def timed(fn, n=20):
+    fn(); fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+bad = 0
+for dt in (torch.bfloat16, torch.float16):
+    for M in (1037, 256 * 7, 129, 4999, 17293):
+        for k, (fn, N, K) in build(M, dt).items():
+            lib.bg_tune_set(10, 2)
+            ref = fn().clone()
+            res = []
+            for al, nar in ((0, 0), (2, 0), (0, 1), (2, 1)):
+                setv(1, al, 7, 0, nar)
+                for rep in range(2):                                  # repeated: a race would not necessarily show the first time
+                    got = fn()
+                    torch.cuda.synchronize()
+                    res.append(torch.equal(ref, got))
+            ok = all(res)
+            bad += not ok
+            if not ok or M == 1037:
+                nd = (ref != got).sum().item()
+                print(f"bit-equal {str(dt)[6:]:9s} M={M:5d} {k:12s} {ok} {res if not ok else ''} {'differing elements: %d' % nd if not ok else ''}")
+print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
+# (name, mode (key 10), align (key 9: 2 = staggered groups), start stagger (key 12: units + 1; 1 = off), nt stores (13), narrow passes (14))
+dt = torch.bfloat16
+VARS = [("128", 2, 0, 0, 0, 0), ("256 nostag", 1, 0, 1, 0, 0), ("256 stag4", 1, 0, 5, 0, 0), ("256 stag6", 1, 0, 7, 0, 0), ("256 stag10", 1, 0, 11, 0, 0),
+        ("256 stag6 nt", 1, 0, 7, 1, 0), ("256 stag6 narrow", 1, 0, 7, 0, 1), ("256 stag6 grp-lag", 1, 2, 7, 0, 0)]
+for M in MS:
+    cases = build(M, dt)
+    res = {(k, v[0]): [] for k in cases for v in VARS}
+    for r in range(5):
+        for name, *kv in VARS:
+            setv(*kv)
+            for k, (fn, N, K) in cases.items():
+                res[(k, name)].append(timed(fn))
+    print(f"M = {M}")
+    for k, (fn, N, K) in cases.items():
+        line = f"  {k:12s}"
+        for name, *kv in VARS:
+            us = statistics.median(res[(k, name)])
+            line += f" | {name} {us:6.1f} {2.0 * M * N * K / us / 1e6:4.0f}"
+        print(line)
+for S in (4096, 8192):
+    a = (rn(S, S) * 0.5).to(dt).to(dev)
+    w = (rn(S, S) * 0.04).to(dt).to(dev)
+    b = rn(S).to(dev)
+    fn = lambda: ops.linear(a, w, b, out_dtype=dt)
+    line = f"square {S}^3 plain:"
+    for name, *kv in VARS:
+        setv(*kv)
+        us = statistics.median(timed(fn, 10) for _ in range(3))
+        line += f" | {name} {us:7.1f} {2.0 * S * S * S / us / 1e6:4.0f}"
+    print(line)
+setv(0, 0, 0, 0, 0)
