@@ -1,11 +1,15 @@
 #!/usr/bin/env python
 """Headline benchmark: denoising-steps/sec, DeepCAD face-LDM, batch=512 per GPU (BASELINE.json configs[1]).
 
-One "step" = one pass of the hot path over one batch: SurfZNet eps-prediction on [512, 60, 48] latents
-(+ face bboxes [512,60,6], key-padding mask, timestep) through bg_denoiser_fwd, the on-device draw of the
-ancestral noise, and the fused DDPM update (bg_cfg_ddpm_step) -- exactly what sample.py:144-153 does per
-iteration.  Synthetic inputs and random-init weights (no datasets / checkpoints offline), all resident in HBM
-before the timed region.  bf16 operands, fp32 accumulation / residual / LayerNorm / softmax.
+The face LDM of the reference is three loops (sample.py:126-202), and one "step" here is one iteration of them -- an
+eps-prediction through bg_denoiser_fwd plus the scheduler update the reference runs in that loop:
+  A  SurfPosNet on [512, 30, 6] boxes        + PNDM update (sample.py:128-137)      158 of the 617 iterations
+  B  SurfPosNet on [512, 60, 6] boxes        + DDPM update, ancestral noise drawn on the device (sample.py:144-153)   250
+  C  SurfZNet  on [512, 60, 48] latents + boxes + key-padding mask (valid faces ~ U{8..60}) + PNDM update (sample.py:191-202)   209
+The K timed steps are split over the three loops in those proportions (A, B, C back to back inside ONE timed region), so
+`value` is the step-weighted face-LDM rate; the per-loop rates are reported beside it (`extra.face_ldm_legs`).
+Synthetic inputs and random-init weights (no datasets / checkpoints offline), all resident in HBM before the timed
+region.  bf16 operands, fp32 accumulation / residual / LayerNorm / softmax.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -26,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_PER_GPU, N_FACE = 512, 60
+# iterations of the three face-LDM loops per sample batch (eval_config.yaml: 200-step PNDM schedule cut at 158 evaluations,
+# the last 250 of 1000 DDPM steps, the full 209-evaluation PNDM schedule), and the per-token I/O FLOPs of SURVEY 8(d)
+LEGS = (("A", "SurfPosNet [512,30,6] + PNDM", 158), ("B", "SurfPosNet [512,60,6] + DDPM", 250), ("C", "SurfZNet [512,60,48]+bbox+mask + PNDM", 209))
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -74,57 +81,95 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(steps=3, warmup=1):
+def split_steps(k):
+    """K face-LDM iterations -> (kA, kB, kC) in the proportions 158 : 250 : 209 of the three loops (each at least 1 when K >= 3)."""
+    tot = sum(w for _, _, w in LEGS)
+    ka, kb = round(k * LEGS[0][2] / tot), round(k * LEGS[1][2] / tot)
+    if k >= 3:
+        ka, kb = max(1, ka), max(1, kb)
+    kc = k - ka - kb
+    if kc < 1 and k >= 3:
+        kb, kc = kb - (1 - kc), 1
+    return ka, kb, kc
+
+
+def cpu_baseline(steps=2, warmup=1):
     """The reference's CPU PyTorch path, timed on this box's host cores on a BOUNDED SAMPLE of the same workload.
 
-    What runs: `oracle/ref_formulation.py` -- the reference's own formulation of SurfZNet (stock
+    What runs: `oracle/ref_formulation.py` -- the reference's own formulation of SurfPosNet / SurfZNet (stock
     nn.TransformerEncoder(norm_first, 12 x 768/12/1024) fed seq-first + Linear-LayerNorm-SiLU-Linear embeds, exactly the
-    library modules network.py:1133-1200 composes; pinned to the reference's outputs by tests/test_oracle_golden.py), fp32,
-    eval / no_grad, with the restated DDPM update.  /root/reference itself cannot travel to the GPU box, hence kind
-    "port".  Sample: the first 128 of the 512 samples (60 tokens each); every op of the path is per-sample, so a full
-    512-batch step costs 4x the sample's time and `value` is reported in the bench's unit with that factor applied.
+    library modules network.py:1080-1200 composes; pinned to the reference's outputs by tests/test_oracle_golden.py), fp32,
+    eval / no_grad, with the restated PNDM / DDPM updates -- the three loops of the headline, `steps` timed iterations each
+    after `warmup`, combined with the same 158 : 250 : 209 weights.  /root/reference itself cannot travel to the GPU box,
+    hence kind "port".  Sample: the first 128 of the 512 samples; every op of the path is per-sample, so a full 512-batch
+    step costs 4x the sample's time and `value` is reported in the bench's unit with that factor applied.
     Threads: torch intra-op threads = PHYSICAL cores (SMT siblings only add contention to GEMM-bound work); a second
-    setting (32) is calibrated on the warm-up step and the faster one is used -- both are reported."""
+    setting (32) is calibrated on a warm-up step of loop C and the faster one is used -- both are reported."""
     from oracle import denoisers as orc
     from oracle import ref_formulation as rf
-    from oracle.schedulers import OracleDDPM
-    sd = orc.seeded_state_dict("SurfZNet", 0)
-    net = rf.build("SurfZNet", sd)
+    from oracle.schedulers import OracleDDPM, OraclePNDM
+    pos_net = rf.build("SurfPosNet", orc.seeded_state_dict("SurfPosNet", 0))
+    z_net = rf.build("SurfZNet", orc.seeded_state_dict("SurfZNet", 0))
     z, pos, mask = make_inputs(B_PER_GPU, "cpu", 1234)
     z, pos, mask = z[:CPU_SAMPLE_B], pos[:CPU_SAMPLE_B], mask[:CPU_SAMPLE_B]
-    sch = OracleDDPM(clip_sample=True, clip_sample_range=3)
-    sch.set_timesteps(1000)
-    ts = sch.timesteps[-250:]
     g = torch.Generator().manual_seed(7)
+    ddpm = OracleDDPM(clip_sample=True, clip_sample_range=3)
+    ddpm.set_timesteps(1000)
+    dts = ddpm.timesteps[-250:]
 
-    def one(i, x):
+    def leg_a():
+        sch = OraclePNDM()
+        sch.set_timesteps(200)
+        x = pos[:, :30].clone()
+        for t in sch.timesteps:
+            x = sch.step(pos_net(x, t.reshape(-1), None), t, x)
+            yield
+
+    def leg_b():
+        x = pos.clone()
+        for t in dts:
+            x = ddpm.step(pos_net(x, t.reshape(-1), None), t, x, noise=torch.randn(x.shape, generator=g))
+            yield
+
+    def leg_c():
+        sch = OraclePNDM()
+        sch.set_timesteps(200)
+        x = z.clone()
+        for t in sch.timesteps:
+            x = sch.step(z_net(x, t.reshape(-1), pos, mask, None), t, x)
+            yield
+
+    def clock(gen, n):
         t0 = time.perf_counter()
-        t = ts[i]
-        eps = net(x, t.reshape(-1), pos, mask, None)
-        x = sch.step(eps, t, x, noise=torch.randn(x.shape, generator=g))
-        return x, time.perf_counter() - t0
+        for _ in range(n):
+            next(gen)
+        return (time.perf_counter() - t0) / n
 
     phys = _physical_cores()
     calib = {}
     with torch.no_grad():
         for n in sorted({phys, min(32, phys)}, reverse=True):
             torch.set_num_threads(n)
-            one(0, z)                                               # page in / build the thread pool
-            calib[n] = one(0, z)[1]
+            it = leg_c()
+            next(it)                                                # page in / build the thread pool
+            calib[n] = clock(it, 1)
         threads = min(calib, key=calib.get)
         torch.set_num_threads(threads)
-        times = []
-        for i in range(warmup + steps):
-            z, dt = one(i, z)
-            if i >= warmup:
-                times.append(dt)
-    per = sum(times) / len(times) * (B_PER_GPU / CPU_SAMPLE_B)
+        per_leg = {}
+        for (key, _, _), fn in zip(LEGS, (leg_a, leg_b, leg_c)):
+            it = fn()
+            clock(it, warmup)
+            per_leg[key] = clock(it, steps)
+    tot = sum(w for _, _, w in LEGS)
+    per = sum(per_leg[k] * w for k, _, w in LEGS) / tot * (B_PER_GPU / CPU_SAMPLE_B)
     return {"value": round(1.0 / per, 4), "unit": "denoising-steps/s (batch=512)", "cores": threads, "kind": "port",
-            "sample": f"{CPU_SAMPLE_B} of the 512 samples x 60 tokens, {steps} timed steps after {warmup} warm-up "
-                      f"(x{B_PER_GPU // CPU_SAMPLE_B} to a full batch: the path is per-sample); the reference's formulation "
-                      "(nn.TransformerEncoder seq-first, oracle/ref_formulation.py) + oracle/schedulers.py, fp32, torch CPU",
-            "s_per_step_batch512": round(per, 3), "threads": threads, "physical_cores": phys,
-            "logical_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
+            "sample": f"{CPU_SAMPLE_B} of the 512 samples, {steps} timed iterations of each of the three face-LDM loops after "
+                      f"{warmup} warm-up, weighted 158:250:209 (x{B_PER_GPU // CPU_SAMPLE_B} to a full batch: the path is "
+                      "per-sample); the reference's formulation (nn.TransformerEncoder seq-first, oracle/ref_formulation.py) + "
+                      "oracle/schedulers.py, fp32, torch CPU",
+            "s_per_step_batch512": round(per, 3),
+            "s_per_leg_step_batch512": {k: round(v * B_PER_GPU / CPU_SAMPLE_B, 3) for k, v in per_leg.items()},
+            "threads": threads, "physical_cores": phys, "logical_cpus": os.cpu_count(), "cpu_model": _cpu_model(),
             "calibration_s_per_sample_step": {str(k): round(v, 3) for k, v in calib.items()}}
 
 
@@ -198,56 +243,97 @@ def edge_net_extra(dev, evals=2):
     return out
 
 
-def face_ldm_extra(dev, steps=20):
-    """The other pieces of the face LDM beside the headline: SurfPosNet [512,60,6] + DDPM update (no mask:
-    dense by construction) and the SurfZNet step with the PNDM update the cascade actually runs for it (sample.py:189-202)."""
-    import brepgen_amd as bga
-    torch.manual_seed(2)
-    out = {}
-    kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001, beta_end=0.02)
-    ddpm = bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw)
-    ddpm.set_timesteps(1000)
-    pndm = bga.PNDMScheduler(**kw)
-    pndm.set_timesteps(200)
-    z, pos, mask = make_inputs(B_PER_GPU, dev, 4321)
+class FaceLDM:
+    """The three loops of the face LDM on the HIP path (one rank's 512 samples), each an endless step generator."""
 
-    def clock(fn, n):
-        fn(0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n):
-            fn(i + 1)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+    def __init__(self, dev, rank, dense=False, split=0):
+        import brepgen_amd as bga
+        from brepgen_amd.sampling import device_randn
+        torch.manual_seed(0)
+        self.dev, self.rank, self._randn = dev, rank, device_randn
+        self.pos_net = bga.SurfPosNet(False).to(dev).eval()
+        self.z_net = bga.SurfZNet(False).to(dev).eval()
+        for n in (self.pos_net, self.z_net):
+            n.compute_dtype = torch.bfloat16
+            if split:
+                n.n_split = split
+        self.z_net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
+        self.z_net.varlen = not dense             # variable-length execution: only the valid faces (U{8..60} of 60) run through the net
+        z, pos, mask = make_inputs(B_PER_GPU, dev, 1234 + rank)
+        self.nvalid = make_inputs.nvalid.double()
+        if self.z_net.varlen:                     # the opt-in profiler books EXECUTED rows / attention pairs (host-side knowledge)
+            self.z_net.profile_hints = (float(self.nvalid.sum()), float((self.nvalid * self.nvalid).sum()))
+        self.pos, self.mask = pos, mask
+        kw = dict(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon", beta_start=0.0001, beta_end=0.02)
+        self.pndm_a, self.pndm_c = bga.PNDMScheduler(**kw), bga.PNDMScheduler(**kw)
+        self.ddpm = bga.DDPMScheduler(clip_sample=True, clip_sample_range=3, **kw)
+        self.ddpm.set_timesteps(1000)
+        self.x = {"A": pos[:, :30].clone(), "B": pos.clone(), "C": z}
+        self.gens = {"A": self._leg_a(), "B": self._leg_b(), "C": self._leg_c()}
 
-    with torch.no_grad():
-        net = bga.SurfPosNet(False).to(dev).eval()
-        net.compute_dtype = torch.bfloat16
-        state = {"x": pos.clone()}
-        ts, ts_dev = ddpm.timesteps[-250:], ddpm.timesteps[-250:].to(dev)
+    def set_split(self, ns):
+        self.pos_net.n_split = self.z_net.n_split = ns
 
-        def surfpos_step(i):
-            eps = net(state["x"], ts_dev[i:i + 1], None)
-            state["x"] = ddpm.step(eps, ts[i], state["x"], noise=torch.randn_like(eps)).prev_sample
-        dt = clock(surfpos_step, steps)
-        f = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 2.38e6)
-        out["surfpos_ddpm_step"] = {"workload": "SurfPosNet eps-eval [512,60,6] + DDPM update, bf16", "ms_per_step": round(dt * 1e3, 3),
-                                    "steps_per_s": round(1 / dt, 2), "model_tflops": round(f / dt / 1e12, 1)}
-        del net
-        net = bga.SurfZNet(False).to(dev).eval()
-        net.compute_dtype = torch.bfloat16
-        net.cache_conditioning = False
-        state = {"x": z.clone()}
-        pts, pts_dev = pndm.timesteps, pndm.timesteps.to(dev)
+    def n_split(self, net):
+        ns = net.n_split
+        return (2 if B_PER_GPU * N_FACE >= 16384 else 1) if ns == "auto" else int(ns)
 
-        def surfz_pndm_step(i):
-            eps = net(state["x"], pts_dev[i:i + 1], pos, mask, None)
-            state["x"] = pndm.step(eps, pts[i], state["x"]).prev_sample
-        dt = clock(surfz_pndm_step, steps)
-        out["surfz_pndm_step"] = {"workload": "SurfZNet eps-eval [512,60,48]+bbox+mask (variable-length) + PNDM update "
-                                              "(PRK warm-up then PLMS), bf16", "ms_per_step": round(dt * 1e3, 3),
-                                  "steps_per_s": round(1 / dt, 2)}
-    return out
+    def _leg_a(self):                             # sample.py:128-137
+        while True:
+            self.pndm_a.set_timesteps(200)
+            ts = self.pndm_a.timesteps[:LEGS[0][2]]
+            tsd = ts.to(self.dev)
+            for i in range(len(ts)):
+                eps = self.pos_net(self.x["A"], tsd[i:i + 1], None)
+                self.x["A"] = self.pndm_a.step(eps, ts[i], self.x["A"]).prev_sample
+                yield
+
+    def _leg_b(self):                             # sample.py:144-153 (noise drawn on the device, keyed on the global sample index)
+        ts = self.ddpm.timesteps[-LEGS[1][2]:]
+        tsd = ts.to(self.dev)
+        draw = 0
+        while True:
+            for i in range(len(ts)):
+                eps = self.pos_net(self.x["B"], tsd[i:i + 1], None)
+                draw += 1
+                noise = self._randn(tuple(self.x["B"].shape), 20240917, draw, self.rank * B_PER_GPU, self.dev)
+                self.x["B"] = self.ddpm.step(eps, ts[i], self.x["B"], noise=noise).prev_sample
+                yield
+
+    def _leg_c(self):                             # sample.py:191-202
+        while True:
+            self.pndm_c.set_timesteps(200)
+            ts = self.pndm_c.timesteps
+            tsd = ts.to(self.dev)
+            for i in range(len(ts)):
+                eps = self.z_net(self.x["C"], tsd[i:i + 1], self.pos, self.mask, None)
+                self.x["C"] = self.pndm_c.step(eps, ts[i], self.x["C"]).prev_sample
+                yield
+
+    def run(self, ka, kb, kc):
+        with torch.no_grad():
+            for key, k in (("A", ka), ("B", kb), ("C", kc)):
+                g = self.gens[key]
+                for _ in range(k):
+                    next(g)
+
+    def flops(self, ka, kb, kc):
+        """(algorithmic, executed) FLOPs of ka + kb + kc iterations (F(N) = N (12 * 7,864,320 + C_io) + 36,864 N^2)."""
+        fa = B_PER_GPU * algorithmic_flops_per_sample_eval(30, 2.38e6)
+        fb = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 2.38e6)
+        fc = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 3.70e6)
+        # executed: F(n_b) summed over the samples (n_b valid faces each); the padded conditioning embed p_embed(surfPos)
+        # (2.44 MFLOP per face) still runs on all 60 faces
+        fc_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), 3.70e6 - 2.44e6) for n in self.nvalid)) + \
+            B_PER_GPU * N_FACE * 2.44e6 if self.z_net.varlen else fc
+        return ka * fa + kb * fb + kc * fc, ka * fa + kb * fb + kc * fc_exec
+
+
+def cascade_extra():
+    """BASELINE configs[2] end to end (tools/cascade_bench.py: the whole DeepCAD cascade + VAE decode, batch 256, bf16)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cascade_bench
+    return cascade_bench.run(256)
 
 
 def pmc_traffic(kernel):
@@ -265,13 +351,13 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the measurements reported beside the headline")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous + JSON only, on CPU (no compute)")
-    ap.add_argument("--dense", action="store_true", help="run every padded position like the reference (no compaction)")
+    ap.add_argument("--dense", action="store_true", help="run every padded position of loop C like the reference (no compaction)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even at world size 1 "
                                                               "(exercises the collective path on a 1-GPU box)")
     ap.add_argument("--split", type=int, default=0, help="sample groups run concurrently on forked streams (0 = the "
@@ -325,88 +411,76 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import brepgen_amd as bga
     from brepgen_amd import _lib
     from brepgen_amd.sampling import gather_latents
 
-    torch.manual_seed(0)
-    net = bga.SurfZNet(False).to(dev).eval()
-    net.compute_dtype = torch.bfloat16
-    net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
-    net.varlen = not args.dense        # variable-length execution: only the valid faces (U{8..60} of 60) run through the net
-    if args.split:
-        net.n_split = args.split       # default "auto": two groups of 256 samples on two streams inside the one C call
-    n_split = 2 if net.n_split == "auto" else int(net.n_split)
-    z, pos, mask = make_inputs(B_PER_GPU, dev, 1234 + rank)
-    nvalid = make_inputs.nvalid.double()
-    if net.varlen:                     # the opt-in profiler books EXECUTED rows / attention pairs (host-side knowledge)
-        net.profile_hints = (float(nvalid.sum()), float((nvalid * nvalid).sum()))
-    sch = bga.DDPMScheduler(num_train_timesteps=1000, beta_schedule="linear", prediction_type="epsilon",
-                            beta_start=0.0001, beta_end=0.02, clip_sample=True, clip_sample_range=3)
-    sch.set_timesteps(1000)
-    ts_cpu = sch.timesteps[-250:]
-    ts_dev = ts_cpu.to(dev)
-
-    def run_steps(k, x, offset=0):
-        with torch.no_grad():
-            for i in range(k):
-                j = (offset + i) % 250
-                eps = net(x, ts_dev[j:j + 1], pos, mask, None)
-                noise = torch.randn_like(x)                          # upstream draws it on the device, per step
-                x = sch.step(eps, ts_cpu[j], x, noise=noise).prev_sample
-        return x
+    ldm = FaceLDM(dev, rank, dense=args.dense, split=args.split)
+    n_split = ldm.n_split(ldm.z_net)
+    ka, kb, kc = split_steps(args.steps)
+    wa, wb, wc = split_steps(max(args.warmup, 3))
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    x = run_steps(args.warmup, z)
+    def latents():
+        return {"surfPos": ldm.x["B"], "surfZ": ldm.x["C"]}
+
+    ldm.run(wa, wb, wc)
     if dist is not None:
-        gather_latents({"surfZ": x}, dist, single_rank_collective=args.force_dist)   # warm the communicator up outside the clock
+        gather_latents(latents(), dist, single_rank_collective=args.force_dist)      # warm the communicator up outside the clock
     barrier()
     t0 = time.perf_counter()
-    x = run_steps(args.steps, x, args.warmup)
-    out = gather_latents({"surfZ": x}, dist, single_rank_collective=args.force_dist) if dist is not None else {"surfZ": x}
+    ldm.run(ka, kb, kc)
+    out = gather_latents(latents(), dist, single_rank_collective=args.force_dist) if dist is not None else latents()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = my_elapsed = time.perf_counter() - t0
+    ranks_seen, per_rank_ms = 1, [round(1e3 * my_elapsed / args.steps, 4)]
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
-    finite = bool(torch.isfinite(out["surfZ"]).all())
+        ones = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)                    # how many ranks really took part
+        ranks_seen = int(ones.item())
+        every = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([my_elapsed], device=dev, dtype=torch.float64))
+        per_rank_ms = [round(1e3 * float(v) / args.steps, 4) for v in every]
+    finite = all(bool(torch.isfinite(v).all()) for v in out.values())
+    flops_cache = ldm.flops(ka, kb, kc)
+
+    def clock(ka_, kb_, kc_):
+        ldm.run(1 if ka_ else 0, 1 if kb_ else 0, 1 if kc_ else 0)
+        barrier()
+        t1 = time.perf_counter()
+        ldm.run(ka_, kb_, kc_)
+        barrier()
+        return time.perf_counter() - t1
 
     extra = {}
-    if n_split > 1 and not args.no_extra:
-        # the same K steps with the launches of a step serialised on one stream (n_split = 1)
-        keep = net.n_split
-        net.n_split = 1
-        run_steps(2, x, 0)
-        barrier()
-        t1 = time.perf_counter()
-        run_steps(args.steps, x, args.warmup)
-        barrier()
-        d_el = time.perf_counter() - t1
-        extra["single_stream_execution"] = {"ms_per_step": round(1e3 * d_el / args.steps, 4),
-                                            "steps_per_s_per_gpu": round(args.steps / d_el, 3)}
-        net.n_split = keep
-    if net.varlen and not args.no_extra:
-        # the same K steps with dense execution (every padded position computed, as the reference does) -- reported
-        # beside the headline, never part of `value`
-        net.varlen, hints = False, net.profile_hints
-        net.profile_hints = None
-        run_steps(2, x, 0)
-        barrier()
-        t1 = time.perf_counter()
-        run_steps(args.steps, x, args.warmup)
-        barrier()
-        d_el = time.perf_counter() - t1
-        extra["dense_execution"] = {"ms_per_step": round(1e3 * d_el / args.steps, 4),
-                                    "steps_per_s_per_gpu": round(args.steps / d_el, 3)}
-        net.varlen, net.profile_hints = True, hints
-    if world == 1 and rank == 0 and not args.no_extra:
-        extra["edge_nets"] = edge_net_extra(dev)
-        extra["face_ldm"] = face_ldm_extra(dev)
+    if not args.no_extra:
+        # each loop on its own (20 iterations), never part of `value`
+        legs = {}
+        for (key, what, w), ks in zip(LEGS, ((20, 0, 0), (0, 20, 0), (0, 0, 20))):
+            d = clock(*ks)
+            fa, fe = ldm.flops(*ks)
+            legs[key] = {"workload": what + ", bf16", "iterations_of_617": w, "ms_per_step": round(1e3 * d / 20, 4),
+                         "steps_per_s_per_gpu": round(20 / d, 2), "executed_tflops": round(fe / d / 1e12, 1)}
+        extra["face_ldm_legs"] = legs
+        if n_split > 1:
+            # the same K steps with the launches of a step serialised on one stream (n_split = 1)
+            ldm.set_split(1)
+            d = clock(ka, kb, kc)
+            extra["single_stream_execution"] = {"ms_per_step": round(1e3 * d / args.steps, 4), "steps_per_s_per_gpu": round(args.steps / d, 3)}
+            ldm.set_split(args.split if args.split else "auto")
+        if ldm.z_net.varlen:
+            # loop C with dense execution (every padded position computed, as the reference does)
+            ldm.z_net.varlen, hints = False, ldm.z_net.profile_hints
+            ldm.z_net.profile_hints = None
+            d = clock(0, 0, 20)
+            extra["dense_execution_loop_C"] = {"ms_per_step": round(1e3 * d / 20, 4), "steps_per_s_per_gpu": round(20 / d, 3)}
+            ldm.z_net.varlen, ldm.z_net.profile_hints = True, hints
 
     roofline = None
     breakdown = None
@@ -414,11 +488,11 @@ def main():
         # second pass of the same K steps with a hipEvent pair around every kernel launch (on the launch stream).  The
         # launches are serialised for it (n_split = 1): with two sample groups in flight every launch shares the CUs with
         # a launch of the other group, and its duration then says nothing about the kernel.
-        keep = net.n_split
-        net.n_split = 1
+        ldm.set_split(1)
+        ldm.run(1, 1, 1)
         with _lib.profile() as prof:
-            run_steps(args.steps, x, args.warmup)
-        net.n_split = keep
+            ldm.run(ka, kb, kc)
+        ldm.set_split(args.split if args.split else "auto")
         rows = {r["kernel"]: r for r in prof.rows}
         breakdown = {k: {"launches": r["launches"], "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                          "total_ms_per_step": round(r["total_ms"] / args.steps, 4),
@@ -428,39 +502,56 @@ def main():
         ach = dom["flops"] / dom["total_ms"] / 1e9                    # TFLOP/s = flops per launch / avg duration
         roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
-                    "launches_per_step": dom["launches"] // args.steps,
+                    "launches_per_step": round(dom["launches"] / args.steps, 2),
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
-                    "flops_per_launch": dom["flops"] / dom["launches"], "flops": "executed (valid rows only)" if net.varlen else "algorithmic",
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "flops": "executed (valid rows only) over the launches of the three loops",
                     "measured_with": "launches serialised (n_split = 1); the timed region runs n_split = %d" % n_split}
+        # every GEMM kernel of the step together (the 256 x 256 kernel takes the row panels that fill whole rounds, the
+        # 128 x 128 kernel the rest and the residual-stream GEMMs): executed FLOPs / their summed durations
+        gem = [r for k, r in rows.items() if k.startswith("gemm16")]
+        if gem:
+            fl, ms = sum(r["flops"] for r in gem), sum(r["total_ms"] for r in gem)
+            roofline["all_16bit_gemm_kernels"] = {"tflops": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                                                  "ms_per_step": round(ms / args.steps, 4)}
+
+    if world == 1 and rank == 0 and not args.no_extra:
+        ldm = None
+        torch.cuda.empty_cache()
+        extra["edge_nets"] = edge_net_extra(dev)
+        try:
+            extra["cascade_cfg3"] = cascade_extra()
+        except Exception as e:                                       # reported, never fatal for the headline
+            extra["cascade_cfg3"] = {"error": repr(e)}
 
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
-        f_step = B_PER_GPU * algorithmic_flops_per_sample_eval(N_FACE, 3.70e6)
-        # executed: F(n_b) summed over the samples (n_b valid faces each); the padded conditioning embed p_embed(surfPos)
-        # (2.44 MFLOP per face) still runs on all 60 faces
-        f_exec = float(sum(algorithmic_flops_per_sample_eval(float(n), 3.70e6 - 2.44e6) for n in nvalid)) + \
-            B_PER_GPU * N_FACE * 2.44e6 if net.varlen else f_step
+        f_alg, f_exec = flops_cache
         line = {
             "metric": "denoising-steps/sec (whole node), DeepCAD face-LDM, batch=512",
             "value": round(steps_per_s, 3), "unit": "denoising-steps/s (batch=512 per step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DeepCAD face-LDM, SurfZNet eps-eval [512,60,48]+bbox+mask "
-                                   "+ DDPM update (timesteps[-250:], clip 3), bf16 operands / fp32 accumulate, per GPU",
+            "config": {"workload": "BASELINE configs[1]: DeepCAD face-LDM = the three loops of sample.py:126-202, step-weighted: "
+                                   f"{ka} x [SurfPosNet [512,30,6] + PNDM], {kb} x [SurfPosNet [512,60,6] + DDPM, device noise], "
+                                   f"{kc} x [SurfZNet [512,60,48]+bbox+mask + PNDM] (158 : 250 : 209), bf16 operands / fp32 accumulate, per GPU",
                        "batch_per_gpu": B_PER_GPU, "tokens_per_sample": N_FACE,
+                       "steps_per_loop": {"A": ka, "B": kb, "C": kc},
                        "sample_steps_per_s": round(steps_per_s * B_PER_GPU, 1),
-                       "algorithmic_tflop_per_step": round(f_step / 1e12, 3),
-                       "executed_tflop_per_step": round(f_exec / 1e12, 3),
-                       "varlen": bool(net.varlen), "n_split": n_split, "valid_faces_per_sample_mean": round(float(nvalid.mean()), 2),
-                       "model_tflops_per_gpu": round(f_step * args.steps / elapsed / 1e12, 1),
-                       "executed_tflops_per_gpu": round(f_exec * args.steps / elapsed / 1e12, 1),
-                       "finite": finite, "parallelism": f"batch-sharded x{world}, 1 all_gather of latents",
-                       "formulation": "two sample groups pipelined on forked streams inside the one C call; "
-                                      "variable-length execution (valid faces compacted on the device; eps = 0 at padded "
-                                      "positions, valid positions as the dense path), norm1/norm2 folded into the QKV/FFN1 "
-                                      "GEMM epilogues, residual stream as (hi, lo) 16-bit planes, fused input embeds; "
-                                      "conditioning cache off (every embed recomputed)"},
+                       "algorithmic_tflop_per_step": round(f_alg / args.steps / 1e12, 3),
+                       "executed_tflop_per_step": round(f_exec / args.steps / 1e12, 3),
+                       "varlen": not args.dense, "n_split": n_split,
+                       "valid_faces_per_sample_mean": round(float(make_inputs.nvalid.double().mean()), 2),
+                       "dense_equivalent_tflops_per_gpu": round(f_alg / elapsed / 1e12, 1),
+                       "executed_tflops_per_gpu": round(f_exec / elapsed / 1e12, 1),
+                       "finite": finite, "ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
+                       "parallelism": f"batch-sharded x{world}, 1 all_gather of latents",
+                       "formulation": ("%d sample group(s) per eps-evaluation on forked streams inside the one C call; " % n_split)
+                                      + ("variable-length execution of loop C (valid faces compacted on the device; eps = 0 at padded "
+                                         "positions, valid positions as the dense path), " if not args.dense else "dense execution, ")
+                                      + "norm1/norm2 folded into the QKV/FFN1 GEMM epilogues, residual stream as (hi, lo) 16-bit planes, "
+                                        "fused input embeds; conditioning cache off (every embed recomputed)"},
             "roofline": roofline, "kernels": breakdown, "extra": extra,
         }
         if world == 1 and not args.no_cpu_baseline:

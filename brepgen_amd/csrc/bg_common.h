@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -125,7 +125,22 @@ struct GemmArgs {
     int cv_C = 0, cv_H = 0, cv_W = 0, cv_kh = 1, cv_kw = 1, cv_up = 0;
     int cv_wo_log2 = 0, cv_ho_log2 = 0, cv_spt_log2 = 0;      // log2 of the output grid and of C / 64 (K-steps per tap)
     const void* cv_zero = nullptr;
+    // ---- 256 + 128 hybrid (set by the launcher only): rows [0, p256_rows(*m_dev, N_pad / 256)) belong to the 256 x 256 kernel,
+    // the rest to the 128 x 128 kernel -- both evaluate the same rule on the device-side row count ----
+    int hybrid = 0;
 };
+
+// Tile-round quantisation: one 256 x 256 tile per CU and round, so a launch whose tile count is a little
+// above a multiple of 256 would spend a whole round on a few tiles.  The 256 kernel therefore takes the whole row panels that
+// fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
+// times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
+constexpr int P256_TAIL_MIN = 160;
+__host__ __device__ inline int p256_rows(int rows, int nt_n256) {
+    const int panels = (rows + 255) >> 8, T = panels * nt_n256;
+    const int R = T >> 8, rem = T - (R << 8);
+    if (rem == 0 || rem >= P256_TAIL_MIN) return panels << 8;
+    return ((R << 8) / nt_n256) << 8;
+}
 
 // 4 x 16-bit (bf16 | fp16) payload <-> floats
 template <bool F16> __device__ __forceinline__ void unpack4_16(uint2 u, float (&f)[4]) {

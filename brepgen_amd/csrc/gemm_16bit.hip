@@ -39,26 +39,10 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// LDS-DMA from inline asm (1 KiB per wave-instruction: lane l's 16 bytes land at lds_wave_base + 16 l).  Unlike the builtin,
-// hipcc does not know about it, so it inserts no vmcnt of its own before later LDS reads: the 8-phase K loop below keeps
-// DMA in flight across several barriers and orders it by hand (counted vmcnt + barrier before the first read).
-__device__ __forceinline__ void lds_dma16_asm(const void* gsrc, void* lds_wave_base) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-
 // BM x BN block tile, WM x WN waves (each wave (BM/WM) x (BN/WN)), STAGES-deep LDS ring over K.
-// KLOOP = 0: one barrier per K-step, all waves in lock-step (every shipped instantiation).
-// KLOOP = 1 (EXPERIMENTAL, bg_tune key 0 = 7; 256 x 256 tile, 2 x 4 waves, 2 buffers): the 8-phase K loop of the CDNA
-//   programming guide (section 5, "the 256^2 8-phase template"), with v_mfma_f32_32x32x16 so that every output element
-//   keeps the k order of the other kernels.  A K-tile is four phases, each = [fragment reads + one half-tile of LDS-DMA]
-//   barrier [8 MFMAs = one 64 x 32 quadrant of the wave's 128 x 64 block] barrier; waves 4-7 run one barrier behind waves
-//   0-3, so on every SIMD one wave is in its MFMA segment while the other reads fragments and issues DMA.  Half-tiles
-//   (A rows 0-127 / 128-255, B rows 0-127 / 128-255 of a buffer) are re-staged two phases after their last read and waited
-//   for with a counted vmcnt one phase before their first read (the schedule is written out next to the loop).
-template <bool F16, int BM, int BN, int WM, int WN, int STAGES, int KLOOP = 0>
+// One barrier per K-step, all waves in lock-step.  (The 8-phase K loop that was tried here as an experimental variant in round 2
+// lives in gemm_p256.hip now, as the K loop of the 256 x 256 persistent kernel.)
+template <bool F16, int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
     using E = Elem<F16>;
     using T = typename E::T;
@@ -113,7 +97,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (KLOOP == 0) {
+    {
         // ---- LDS-DMA source addresses (per lane), destination bases (per wave) ----
         constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;   // wave-instructions per wave per stage
         constexpr int PER_STAGE = A_INSTR + B_INSTR;
@@ -209,131 +193,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
         int kt = 0;
         for (; kt + STAGES - 1 < KT; ++kt) ktile(kt, std::true_type{});
         for (; kt < KT; ++kt) ktile(kt, std::false_type{});
-    } else {
-        // ================= KLOOP 1: the 8-phase loop (256 x 256 tile, 8 waves as 2 x 4, two 64 KiB buffers) =================
-        static_assert(KLOOP == 0 || (BM == 256 && BN == 256 && WM == 2 && WN == 4 && STAGES == 2), "8-phase geometry");
-        // Half-tile h4 of a buffer: 0 = A rows 0-127, 1 = A rows 128-255, 2 = B rows 0-127, 3 = B rows 128-255 (16 KiB each).
-        // Every wave moves two of its sixteen 1-KiB pieces (8 rows x 128 B): pieces `wave` and `wave + 8`.
-        // Addresses as a wave-uniform base (SGPR pair: tile origin + k offset) plus a 32-bit per-lane byte offset -- eight
-        // VGPRs instead of sixteen for eight 64-bit pointers, which is what keeps this loop free of spills.
-        unsigned hoff[4][2];
-#pragma unroll
-        for (int h4 = 0; h4 < 4; ++h4)
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int row = (h4 & 1) * 128 + (wave + 8 * r) * 8 + (lane >> 3);      // row inside the A (or B) tile
-                const int c = (lane & 7) ^ ((row >> 1) & 7);
-                if (h4 < 2) {
-                    int grow = m0 + row;
-                    grow = grow < Mv ? grow : Mv - 1;
-                    hoff[h4][r] = (unsigned)(grow - m0) * (unsigned)g.lda * 2u + (unsigned)c * 16u;
-                } else {
-                    hoff[h4][r] = (unsigned)row * (unsigned)g.K * 2u + (unsigned)c * 16u;
-                }
-            }
-        const unsigned char* a_tile = reinterpret_cast<const unsigned char*>(A + (size_t)m0 * g.lda);
-        const unsigned char* w_tile = reinterpret_cast<const unsigned char*>(W + (size_t)n0 * g.K);
-        auto stage = [&](int buf, int h4, int k0) {
-            unsigned char* base = lds + buf * STAGE_BYTES + h4 * (128 * 128);
-            const unsigned char* src = (h4 < 2 ? a_tile : w_tile) + (size_t)k0 * 2;
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) void*)(base + (wave + 8 * r) * 1024));
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(hoff[h4][r]), "s"(src), "s"(dst) : "memory");
-            }
-        };
-        const int KT = g.K / G_BK;                                // even (launcher)
-        V8 fa[2][2][4], fb[4];                                    // A sub-tiles qm = 0, 1 (2 row tiles x 4 k-slices), one B sub-tile
-        auto read_a = [&](const unsigned char* st, int qm) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    fa[qm][i][ks] = *reinterpret_cast<const V8*>(st + a_off[2 * qm + i] + (((ks * 2 + h) ^ a_sw[2 * qm + i]) << 4));
-        };
-        auto read_b = [&](const unsigned char* st, int qn) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                fb[ks] = *reinterpret_cast<const V8*>(st + b_off[qn] + (((ks * 2 + h) ^ b_sw[qn]) << 4));
-        };
-        auto quadrant = [&](int qm, int qn) {                     // 8 MFMAs: rows qm*64..+63 x columns qn*32..+31 of the wave's block
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[2 * qm + i][qn] = E::mfma(fa[qm][i][ks], fb[ks], acc[2 * qm + i][qn]);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto bar = [&]() {                                        // raw barrier; nothing -- at IR or machine level -- moves across it
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::: "memory");
-        };
-        // ---- prologue: buffer 0 complete, the two A halves of buffer 1 in flight (as if issued in phases 7, 8) ----
-        stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
-        if (KT > 1) { stage(1, 0, G_BK); stage(1, 1, G_BK); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
-        bar();
-        if (wm == 1) bar();                                       // waves 4-7 run one barrier behind
-        // ---- steady state: per iteration two K-tiles, t (buffer 0) and t + 1 (buffer 1).  Phase p of the iteration:
-        //   p   reads (buffer)        LDS-DMA issued (2 per wave)       wait            MFMAs
-        //   1   B q0, A q0   (0)      buffer 1, B rows   0-127 (t+1)                    Q00
-        //   2   A q1         (0)      buffer 1, B rows 128-255 (t+1)                    Q10
-        //   3   B q1         (0)      buffer 0, A rows   0-127 (t+2)                    Q11
-        //   4   --                    buffer 0, A rows 128-255 (t+2)    vmcnt(4)        Q01   -> buffer 1 (t+1) landed
-        //   5   B q0, A q0   (1)      buffer 0, B rows   0-127 (t+2)                    Q00
-        //   6   A q1         (1)      buffer 0, B rows 128-255 (t+2)                    Q10
-        //   7   B q1         (1)      buffer 1, A rows   0-127 (t+3)                    Q11
-        //   8   --                    buffer 1, A rows 128-255 (t+3)    vmcnt(4)        Q01   -> buffer 0 (t+2) landed
-        // Write-after-read: A rows 0-127 are read by waves 0-3 only (phases 1, 2 / 5, 6), A rows 128-255 by waves 4-7 one
-        // barrier later, B by everybody (phases 1, 3 / 5, 7); each half is re-staged >= 2 barriers after the lgkmcnt(0) that
-        // retired its last read.  Read-after-write: the counted vmcnt sits before the first barrier of phases 4 / 8, the
-        // first read of that buffer in phase 5 / 1 -- two barriers later for waves 0-3, three for waves 4-7.
-        const unsigned char* b0 = lds;
-        const unsigned char* b1 = lds + STAGE_BYTES;
-        for (int t = 0; t < KT; t += 2) {
-            const bool more = t + 2 < KT;                         // K-tiles t + 2, t + 3 exist (KT is even)
-            const int k1 = (t + 1) * G_BK, k2 = (t + 2) * G_BK, k3 = (t + 3) * G_BK;
-            // phase 1
-            read_b(b0, 0); __builtin_amdgcn_sched_barrier(0); read_a(b0, 0);
-            stage(1, 2, k1);
-            bar(); quadrant(0, 0); bar();
-            // phase 2
-            read_a(b0, 1);
-            stage(1, 3, k1);
-            bar(); quadrant(1, 0); bar();
-            // phase 3
-            read_b(b0, 1);
-            if (more) stage(0, 0, k2);
-            bar(); quadrant(1, 1); bar();
-            // phase 4
-            if (more) { stage(0, 1, k2); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
-            bar(); quadrant(0, 1); bar();
-            // phase 5
-            read_b(b1, 0); __builtin_amdgcn_sched_barrier(0); read_a(b1, 0);
-            if (more) stage(0, 2, k2);
-            bar(); quadrant(0, 0); bar();
-            // phase 6
-            read_a(b1, 1);
-            if (more) stage(0, 3, k2);
-            bar(); quadrant(1, 0); bar();
-            // phase 7
-            read_b(b1, 1);
-            if (more) stage(1, 0, k3);
-            bar(); quadrant(1, 1); bar();
-            // phase 8
-            if (more) { stage(1, 1, k3); wait_vmcnt<4>(); }
-            bar(); quadrant(0, 1); bar();
-        }
-        if (wm == 0) bar();                                       // pairs with the extra barrier of waves 4-7
     }
     __syncthreads();                                              // all fragment reads done: LDS is free
 
@@ -495,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int G = gridDim.x;
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
+    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
     // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
     // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
     // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
@@ -504,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int first_l = xcd_remap(blockIdx.x, G);                 // walk 1: tiles first_l, first_l + G, ... in row-major order
     auto tile_at = [&](int t, int& tm0, int& tn0) -> bool {
         if (walk == 1) {
-            const int L = first_l + ((t - w_local) / cnt) * G;
+            const int L = first_l + ((t - w_local) / cnt) * G + p0 * nt_n;
             tm0 = (L / nt_n) * BM;
             tn0 = (L % nt_n) * BN;
             return L < m_panels * nt_n;
         }
-        const int panel = mg + (t / ngt) * mgs;
+        const int panel = p0 + mg + (t / ngt) * mgs;
         tm0 = panel * BM;
         tn0 = (gx * ngt + t % ngt) * BN;
         return panel < m_panels;
@@ -932,10 +792,23 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 }
 
 
+// opt-in profiler accounting of `rows` output rows: 2 M N K flops; bytes = operands once + output once (+ addends)
+static void gemm_cost(const GemmArgs& g, double rows, double& flops, double& bytes) {
+    const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
+    flops = 2.0 * rows * g.N * (double)g.K;
+    bytes = 2.0 * rows * g.K + 2.0 * g.N * (double)g.K + osz * rows * g.N + (g.add ? 4.0 * (rows / g.add_div) * g.N : 0.0) +
+            (g.add2 ? 4.0 * (rows / g.add2_div) * g.N : 0.0);
+}
+
 template <bool F16>
 static int launch16(const GemmArgs& g, hipStream_t s) {
+    const double rows_all = g.rows_hint > 0 ? g.rows_hint : g.M;  // (profiler accounting only)
+    double rows_tail = rows_all;
     const int m128 = (g.M + 127) / 128, m256 = (g.M + 255) / 256, n128 = g.N_pad / 128;
     if (g.N_pad % 128 != 0) {                                     // narrow outputs (fc_out.3: 6/18/48 -> padded 64; conv_out 3)
+        double fl, by;
+        gemm_cost(g, rows_all, fl, by);
+        ProfScope prof(PK_GEMM_BF16_64, fl, by, s);
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 64, 4, 1, 2>), dim3(m128 * (g.N_pad / 64)), dim3(256), 0, s, g);
         return launch_status("gemm16");
     }
@@ -950,23 +823,50 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;
     }
-    // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs once a launch has enough tiles to fill
-    // the chip (bg_tune key 10: 0 = by tile count, 1 = wherever eligible, 2 = never; key 11 overrides the tile threshold)
+    // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs, on the row panels that fill complete
+    // rounds of 256 tiles; the 128 x 128 kernel below runs the remaining rows (bg_common.h: p256_rows).  With a device-side row
+    // count the split is only known on the device: both kernels are launched and evaluate the same rule.
+    // bg_tune key 10: 0 = hybrid, 1 = 256 kernel alone wherever eligible, 2 = never.
+    bool tail_only = false;
     if (variant == 0 && g_tune[TUNE_P256_MODE] != 2 && p256_eligible(g)) {
-        const int t256 = m256 * (g.N_pad / 256);
-        const int thr = g_tune[TUNE_P256_MIN_TILES] > 0 ? g_tune[TUNE_P256_MIN_TILES] : 192;
-        if (g_tune[TUNE_P256_MODE] == 1 || t256 >= thr) return launch_p256<F16>(g, s);
+        double fl, by;
+        if (g_tune[TUNE_P256_MODE] == 1) {
+            gemm_cost(g, rows_all, fl, by);
+            ProfScope prof(PK_GEMM_P256, fl, by, s);
+            return launch_p256<F16>(g, s);
+        }
+        const int rows_hi = p256_rows(g.M, g.N_pad / 256);        // upper bound of what the 256 kernel may own
+        const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK);
+        if (rows_hi > 0 && can_tail) {
+            GemmArgs h = g;
+            h.hybrid = 1;
+            const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256), rows_all);
+            rows_tail = rows_all - rows_p;
+            gemm_cost(g, rows_p, fl, by);
+            int rc;
+            {
+                ProfScope prof(PK_GEMM_P256, fl, by, s);
+                rc = launch_p256<F16>(h, s);
+            }
+            if (rc) return rc;
+            if (g.m_dev == nullptr && rows_hi >= g.M) return 0;   // dense and everything fitted
+            tail_only = true;
+        }
     }
+    GemmArgs gt = g;
+    gt.hybrid = tail_only ? 1 : 0;
+    const GemmArgs& g_ = gt;
+    double fl_t, by_t;
+    gemm_cost(g, rows_tail, fl_t, by_t);
+    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, fl_t, by_t, s);
     if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
-        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g);
+        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g_);
     } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
-        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g);
-    } else if (variant == 7 && g.N_pad % 256 == 0 && (g.K / G_BK) % 2 == 0) {   // EXPERIMENTAL: 256x256 with the 8-phase K loop
-        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 256, 2, 4, 2, 1>), dim3(m256 * (g.N_pad / 256)), dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g_);
     } else if (variant == 6 && g.N_pad % 256 == 0) {              // 256x256, 8 waves (128x64 per wave), 2-stage ring
-        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 256, 2, 4, 2>), dim3(m256 * (g.N_pad / 256)), dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 256, 2, 4, 2>), dim3(m256 * (g.N_pad / 256)), dim3(512), 0, s, g_);
     } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
-        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g);
+        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g_);
     } else {
         // 2 resident workgroups per CU x 256 CUs, multiple of 8.  (bg_tune key 3 caps it -- 256 = one workgroup per CU, so
         // that the GEMM of a second, independent stream can be co-resident: tools/dual_stream_probe.py)
@@ -984,18 +884,18 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (variant == 31 && g.out_lo == nullptr && g.stats_in == nullptr) {   // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
-            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], dbg);
+            if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
+            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.out_lo) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.stats_in) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (fast) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         }
     }
     return launch_status("gemm16");
@@ -1032,12 +932,6 @@ int gemm_16bit(const GemmArgs& g, int ab_dtype, hipStream_t s) {
             return BG_E_ARG;
         }
     }
-    // algorithmic cost: 2*M*N*K flops; bytes = operands once + output once (+ addends)
-    const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
-    const double rows = g.rows_hint > 0 ? g.rows_hint : g.M;
-    const double bytes = 2.0 * rows * g.K + 2.0 * g.N * (double)g.K + osz * rows * g.N +
-                         (g.add ? 4.0 * (rows / g.add_div) * g.N : 0.0) + (g.add2 ? 4.0 * (rows / g.add2_div) * g.N : 0.0);
-    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, 2.0 * rows * g.N * (double)g.K, bytes, s);
     return ab_dtype == BG_F16 ? launch16<true>(g, s) : launch16<false>(g, s);
 }
 

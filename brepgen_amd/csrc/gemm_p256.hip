@@ -71,7 +71,8 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
 
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     const int nt_n = g.N_pad >> 8;
-    const int T_all = ((Mv + 255) >> 8) * nt_n;
+    // (hybrid launches: only the row panels that fill complete rounds -- the 128 x 128 kernel runs the rest, bg_common.h)
+    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n) >> 8) : ((Mv + 255) >> 8)) * nt_n;
     const int G = gridDim.x;
     // XCD-aware walk: workgroup b (on XCD b % 8) owns tiles first, first + G, ... of the row-major tile list, `first` being
     // consecutive for the workgroups of one XCD -- the ~32 tiles an XCD runs at a time cover 3-4 row panels x all column tiles, so
@@ -155,30 +156,50 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     // upper half 2, 3 (row tile i -> row m0 + wm*128 + 32 i + l31), each from the row's 12 partial (sum, sum of squares) pairs in
     // the association order every kernel uses (tree16).  Load and use are separate calls so that the epilogue can put its own
     // work in between.
-    struct RowStats { f32x16 lo; f32x8 hi; };                     // 12 (sum, sum of squares) pairs as SSA values (never an array in
-                                                                  // memory: hipcc left a float2[12] on the stack, one waited load at a time)
-    auto stats_load = [&](int m0t, int ii) -> RowStats {         // this half wave's row tile 2 h + ii
+    // The row statistics are loaded by inline asm: hipcc's own bookkeeping ignores the younger stores when it waits for a load (it
+    // would wait for vmcnt(0), i.e. until every store of this epilogue has been acknowledged); here the loads are issued ahead of
+    // the epilogue's 16 stores and waited for with the exact count behind them.  Both row tiles of the half wave: 24 loads of 8 B.
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    struct RowStats { f32x2 v[2][FOLD_PARTS]; };
+    auto stats_issue = [&](int m0t, RowStats& r, int ii) {
         const int ln = opaque(threadIdx.x & 63);
-        int grow = m0t + wm * 128 + (2 * (ln >> 5) + ii) * 32 + (ln & 31);
-        grow = grow < Mv ? grow : Mv - 1;
-        const float2* sp = reinterpret_cast<const float2*>(g.stats_in) + grow;                 // part-major: [K/64][M] pairs
-        RowStats r;
+        {
+            int grow = m0t + wm * 128 + (2 * (ln >> 5) + ii) * 32 + (ln & 31);
+            grow = grow < Mv ? grow : Mv - 1;
+            const unsigned voff = (unsigned)grow * 8u;            // part-major [K/64][M] pairs: part p at + p * M * 8 bytes
 #pragma unroll
-        for (int p = 0; p < 8; ++p) { const float2 v = sp[(size_t)p * g.M]; r.lo[2 * p] = v.x; r.lo[2 * p + 1] = v.y; }
-#pragma unroll
-        for (int p = 8; p < FOLD_PARTS; ++p) { const float2 v = sp[(size_t)p * g.M]; r.hi[2 * (p - 8)] = v.x; r.hi[2 * (p - 8) + 1] = v.y; }
-        return r;
-    };
-    auto stats_coeffs = [&](RowStats r, int ii) {
-        const int ln = opaque(threadIdx.x & 63);
-        float ps[16], pq[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            ps[p] = p < 8 ? r.lo[2 * (p & 7)] : (p < FOLD_PARTS ? r.hi[2 * (p & 3)] : 0.f);
-            pq[p] = p < 8 ? r.lo[2 * (p & 7) + 1] : (p < FOLD_PARTS ? r.hi[2 * (p & 3) + 1] : 0.f);
+            for (int p = 0; p < FOLD_PARTS; ++p) {
+                const unsigned char* base = reinterpret_cast<const unsigned char*>(g.stats_in) + (size_t)p * g.M * 8;
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.v[ii][p]) : "v"(voff), "s"(base) : "memory");
+            }
         }
-        reinterpret_cast<float2*>(patch + 2560)[(2 * (ln >> 5) + ii) * 32 + (ln & 31)] =
-            ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+    };
+    // YOUNGER = number of vector-memory instructions issued since stats_issue (they retire in order)
+    auto stats_wait = [&](RowStats& r, auto younger_c) {
+        constexpr int YOUNGER = decltype(younger_c)::value;
+        asm volatile("s_waitcnt vmcnt(%12)"
+                     : "+v"(r.v[0][0]), "+v"(r.v[0][1]), "+v"(r.v[0][2]), "+v"(r.v[0][3]), "+v"(r.v[0][4]), "+v"(r.v[0][5]),
+                       "+v"(r.v[0][6]), "+v"(r.v[0][7]), "+v"(r.v[0][8]), "+v"(r.v[0][9]), "+v"(r.v[0][10]), "+v"(r.v[0][11])
+                     : "n"(YOUNGER) : "memory");
+        asm volatile(""
+                     : "+v"(r.v[1][0]), "+v"(r.v[1][1]), "+v"(r.v[1][2]), "+v"(r.v[1][3]), "+v"(r.v[1][4]), "+v"(r.v[1][5]),
+                       "+v"(r.v[1][6]), "+v"(r.v[1][7]), "+v"(r.v[1][8]), "+v"(r.v[1][9]), "+v"(r.v[1][10]), "+v"(r.v[1][11])
+                     :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stats_coeffs = [&](const RowStats& r) {                  // -> the coefficient slots of the patch
+        const int ln = opaque(threadIdx.x & 63);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            float ps[16], pq[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                ps[p] = p < FOLD_PARTS ? r.v[ii][p < FOLD_PARTS ? p : 0][0] : 0.f;
+                pq[p] = p < FOLD_PARTS ? r.v[ii][p < FOLD_PARTS ? p : 0][1] : 0.f;
+            }
+            reinterpret_cast<float2*>(patch + 2560)[(2 * (ln >> 5) + ii) * 32 + (ln & 31)] =
+                ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+        }
     };
 
     // ---- fragment read addresses inside a buffer (A rows first, W rows at +32 KiB) ----
@@ -231,7 +252,13 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     const unsigned char* a_cur = Ab + (size_t)m0 * lda_b;
     const unsigned char* w_cur = Wb + (size_t)n0 * ldw_b;
     a_offsets(m0);
-    if (FOLD) { stats_coeffs(stats_load(m0, 0), 0); stats_coeffs(stats_load(m0, 1), 1); }
+    if (FOLD) {
+        RowStats r;
+        stats_issue(m0, r, 0);
+        stats_issue(m0, r, 1);
+        stats_wait(r, std::integral_constant<int, 0>{});
+        stats_coeffs(r);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stage_cols(n0);
 
@@ -306,13 +333,15 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
             const int rbase = m0 + wm * 128, cbase = n0 + wn * 64;
             T* out = reinterpret_cast<T*>(g.out);
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            // Unconditional: a row past the end computed on a copy of row Mv - 1 (the A rows are clamped, so are its LayerNorm
+            // statistics) and holds that row's exact values -- it is stored over row Mv - 1 again.  Every tile thus issues the same
+            // number of stores, which the counted wait of the LayerNorm-fold epilogue relies on.
             auto store16 = [&](int grow, int col, uint4 v) {
-                if (grow < Mv) {
-                    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
-                    const u32x4 vv = {v.x, v.y, v.z, v.w};
-                    if (nt_stores) __builtin_nontemporal_store(vv, dst);
-                    else *dst = vv;
-                }
+                grow = grow < Mv ? grow : Mv - 1;
+                u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
+                const u32x4 vv = {v.x, v.y, v.z, v.w};
+                if (nt_stores) __builtin_nontemporal_store(vv, dst);
+                else *dst = vv;
             };
             // one accumulator quad (row l31 of row tile i, columns j*32 + 8 q + 4 hq .. +3) -> 4 x 16 bit
             auto quad = [&](int i, int j, int q, float4 b, float4 c, float2 cf) -> uint2 {
@@ -385,17 +414,20 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                     }
                     __builtin_amdgcn_wave_barrier();
                 };
-                // The next tile's row statistics are requested between the passes -- accumulator registers are free by then -- and
-                // turned into coefficients a few passes later: their latency hides behind this epilogue's own work.  The
-                // coefficient slots of row tiles 0, 1 (2, 3) are free once the passes of those row tiles are done.
-                pass(0, 0); pass(0, 1); pass(1, 0); pass(1, 1);
-                // (unconditional: without a next tile the clamped rows are loaded and the results never read)
+                // The next tile's row statistics are requested ahead of the passes (second row tile: once half of the accumulators
+                // are free) and turned into coefficients behind them -- exactly 8 stores younger than the last load: their
+                // latency hides behind this epilogue's own work.  Unconditional: without a next tile the clamped rows are loaded
+                // and the results never read.
+                RowStats rs;
+                if (FOLD) stats_issue(m0n, rs, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                const RowStats rs = stats_load(m0n, 0);
+                pass(0, 0); pass(0, 1); pass(1, 0); pass(1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FOLD) stats_issue(m0n, rs, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 pass(2, 0); pass(2, 1); pass(3, 0); pass(3, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FOLD) { stats_coeffs(rs, 0); stats_coeffs(stats_load(m0n, 1), 1); }
+                if (FOLD) { stats_wait(rs, std::integral_constant<int, 8>{}); stats_coeffs(rs); }
             }
             if (has_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the patch accesses above are complete
@@ -420,12 +452,13 @@ bool p256_eligible(const GemmArgs& g) {
 
 template <bool F16>
 int launch_p256(const GemmArgs& g, hipStream_t s) {
-    const int tiles = ((g.M + 255) / 256) * (g.N_pad / 256);
+    const int tiles = ((g.hybrid ? p256_rows(g.M, g.N_pad / 256) : g.M + 255) / 256) * (g.N_pad / 256);   // upper bound (varlen: g.M)
+    if (tiles == 0) return 0;
     const int grid = tiles < 256 ? tiles : 256;
     const int align = g_tune[TUNE_P256_ALIGN] != 2;               // bg_tune key 9: 2 = wave groups enter the epilogue one barrier apart
-    // start stagger (see the kernel): 32 cohorts x units x 64 cycles; only when a workgroup walks at least two tiles
-    const int units = g_tune[TUNE_P256_STAGGER] > 0 ? g_tune[TUNE_P256_STAGGER] - 1 : 6;
-    const int stg = tiles >= 2 * 256 - 64 ? units : 0;
+    // start stagger (see the kernel; bg_tune key 12 = units + 1): measured a loss at every setting (profiles/r03/
+    // gemm_p256_knob_sweep.log: lock-step workgroups share their A / W fetches in the L2), so it is off unless asked for
+    const int stg = g_tune[TUNE_P256_STAGGER] > 1 && tiles >= 2 * 256 - 64 ? g_tune[TUNE_P256_STAGGER] - 1 : 0;
     const int nt = g_tune[TUNE_P256_NT];
     if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else if (g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);

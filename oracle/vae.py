@@ -140,10 +140,10 @@ def _attn1d(sd, p, x):
 def upsample1d_cubic(x):
     """diffusers Upsample1d("cubic") exactly as upstream builds it: dense diagonal transposed conv."""
     C = x.shape[1]
-    k = torch.tensor(CUBIC, dtype=x.dtype) * 2
+    k = torch.tensor(CUBIC, dtype=x.dtype, device=x.device) * 2
     xp = F.pad(x, (2, 2), mode="reflect")
     w = x.new_zeros(C, C, 8)
-    idx = torch.arange(C)
+    idx = torch.arange(C, device=x.device)
     w[idx, idx] = k
     return F.conv_transpose1d(xp, w, stride=2, padding=7)
 
@@ -265,10 +265,10 @@ def surf_encoder_spec(block_out=(128, 256, 512, 512), layers_per_block=2, latent
 def downsample1d_cubic(x):
     """diffusers Downsample1d("cubic"): reflect pad 3, dense-diagonal stride-2 conv with the 8-tap kernel."""
     C = x.shape[1]
-    k = torch.tensor(CUBIC, dtype=x.dtype)
+    k = torch.tensor(CUBIC, dtype=x.dtype, device=x.device)
     xp = F.pad(x, (3, 3), mode="reflect")
     w = x.new_zeros(C, C, 8)
-    idx = torch.arange(C)
+    idx = torch.arange(C, device=x.device)
     w[idx, idx] = k
     return F.conv1d(xp, w, stride=2)
 

@@ -319,7 +319,21 @@ def oracle_case(net, B, S, E, dtype, use_cf=False, seed=7, varlen=False):
     return e
 
 
-def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3, last=None):
+_SD_DEV = {}
+
+
+def oracle_on_device(fn, sd, *args):
+    """The fp32 oracle forward `fn(sd, *args)` evaluated on the GPU (plain torch; gfx950 has no TF32) and returned on the CPU:
+    the chain / cascade tests call the oracle hundreds of times on tiny batches, which costs ~0.2 s per call on the host."""
+    key = id(sd)
+    if key not in _SD_DEV:
+        _SD_DEV[key] = ({k: v.to(DEV) for k, v in sd.items()}, sd)      # (keep sd alive: the cache is keyed on its id)
+    mv = lambda a: a.to(DEV) if torch.is_tensor(a) else a
+    with torch.no_grad():
+        return fn(_SD_DEV[key][0], *[mv(a) for a in args]).cpu()
+
+
+def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3, last=None, oracle_dev=True):
     """BASELINE configs[0]: B=1 face-LDM, `steps` DDPM steps of SurfZNet with injected noise, HIP vs oracle.
     Both chains are fed the ORACLE's trajectory (per-step parity: same x_t in, compare x_{t-1} out)."""
     m, sd = build_net("SurfZNet", seed, False, dtype)
@@ -339,7 +353,7 @@ def ddpm_chain_case(dtype, steps=50, B=1, N=60, seed=3, last=None):
         for t in (s.timesteps if last is None else s.timesteps[-last:]):
             noise = torch.randn(B, N, 48, generator=g)
             tt = t.reshape(-1)
-            eo = orc.surfz_forward(sd, x, tt, surfPos, mask)
+            eo = oracle_on_device(orc.surfz_forward, sd, x, tt, surfPos, mask) if oracle_dev else orc.surfz_forward(sd, x, tt, surfPos, mask)
             xo = o.step(eo, t, x, noise=noise)
             eh = m(x.to(DEV), tt.to(DEV), sp_d, mk_d, None)
             xh = s.step(eh, t, x.to(DEV), noise=noise.to(DEV)).prev_sample

@@ -1,5 +1,6 @@
-"""-m gpu: the whole denoising cascade (sample.py:120-286) on the HIP path vs the same cascade driven by the CPU
-oracle (oracle nets + restated schedulers + the same seeded CPU noise), fp32, shortened schedules."""
+"""-m gpu: the whole denoising cascade (sample.py:120-286) on the HIP path vs the same cascade driven by the oracle
+(oracle nets -- their fp32 forwards evaluated with plain torch on the device -- + restated schedulers, de-duplication and
+the same seeded noise on the CPU), fp32, shortened schedules."""
 import numpy as np
 import pytest
 import torch
@@ -14,6 +15,7 @@ def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, 
     from brepgen_amd.utils import randn_tensor
     from oracle import denoisers as orc
     from oracle.schedulers import OracleDDPM, OraclePNDM
+    from parity_cases import oracle_on_device as on_dev           # the oracle's fp32 forwards run on the GPU (~70 tiny evaluations)
     pndm, ddpm = OraclePNDM(), OracleDDPM(clip_sample=True, clip_sample_range=3)
     cl = torch.tensor([class_id] * B + [0] * B).reshape(-1, 1) if use_cf else None
     rep = (lambda t: t.repeat(2, *([1] * (t.dim() - 1)))) if use_cf else (lambda t: t)
@@ -24,35 +26,35 @@ def _oracle_cascade(sds, B, S, E, gen, use_cf, class_id, w, n_pos, n_ddpm, n_z, 
     x = randn_tensor((B, S, 6), generator=gen)
     pndm.set_timesteps(200)
     for t in pndm.timesteps[:n_pos]:
-        x = pndm.step(guided(orc.surfpos_forward(sds[0], rep(x), t.reshape(-1), cl)), t, x)
+        x = pndm.step(guided(on_dev(orc.surfpos_forward, sds[0], rep(x), t.reshape(-1), cl)), t, x)
     if not use_cf:
         x = x.repeat(1, 2, 1)
         S *= 2
     ddpm.set_timesteps(1000)
     for t in ddpm.timesteps[-n_ddpm:]:
         z = randn_tensor((B, S, 6), generator=gen) if int(t) > 0 else None
-        x = ddpm.step(guided(orc.surfpos_forward(sds[0], rep(x), t.reshape(-1), cl)), t, x, noise=z)
+        x = ddpm.step(guided(on_dev(orc.surfpos_forward, sds[0], rep(x), t.reshape(-1), cl)), t, x, noise=z)
     surfPos, surfMask = dedup_surfaces(x, thr)
     surfZ = randn_tensor((B, S, 48), generator=gen)
     pndm.set_timesteps(200)
     for t in pndm.timesteps[:n_z]:
-        surfZ = pndm.step(guided(orc.surfz_forward(sds[1], rep(surfZ), t.reshape(-1), rep(surfPos), rep(surfMask), cl)),
+        surfZ = pndm.step(guided(on_dev(orc.surfz_forward, sds[1], rep(surfZ), t.reshape(-1), rep(surfPos), rep(surfMask), cl)),
                           t, surfZ)
     edgePos = randn_tensor((B, S, E, 6), generator=gen)
     pndm.set_timesteps(200)
     for t in pndm.timesteps[:n_pos]:
-        e = orc.edgepos_forward(sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
+        e = on_dev(orc.edgepos_forward, sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
         edgePos = pndm.step(guided(e), t, edgePos)
     ddpm.set_timesteps(1000)
     for t in ddpm.timesteps[-n_ddpm:]:
         z = randn_tensor((B, S, E, 6), generator=gen) if int(t) > 0 else None
-        e = orc.edgepos_forward(sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
+        e = on_dev(orc.edgepos_forward, sds[2], rep(edgePos), t.reshape(-1), rep(surfPos), rep(surfZ), rep(surfMask), cl)
         edgePos = ddpm.step(guided(e), t, edgePos, noise=z)
     edgeM = dedup_edges(edgePos, surfMask, thr)
     edgeZV = randn_tensor((B, S, E, 18), generator=gen)
     pndm.set_timesteps(200)
     for t in pndm.timesteps[:n_z]:
-        e = orc.edgez_forward(sds[3], rep(edgeZV), t.reshape(-1), rep(edgePos), rep(surfPos), rep(surfZ), rep(edgeM), cl)
+        e = on_dev(orc.edgez_forward, sds[3], rep(edgeZV), t.reshape(-1), rep(edgePos), rep(surfPos), rep(surfZ), rep(edgeM), cl)
         edgeZV = pndm.step(guided(e), t, edgeZV)
     edgeZV = edgeZV.masked_fill(edgeM.unsqueeze(-1), 0.0)
     return dict(surfPos=surfPos, surfMask=surfMask, surfZ=surfZ, edgePos=edgePos, edgeM=edgeM, edgeZV=edgeZV)

@@ -222,8 +222,9 @@ def test_denoiser_vs_oracle_larger(pc):
 
 def test_baseline_config0_ddpm_chain(pc):
     """BASELINE configs[0]: B=1 face-LDM, 50 DDPM steps with injected noise, per-step parity."""
-    e = pc.ddpm_chain_case(F32, steps=50)
-    assert e["finite"] and e["max_abs_eps"] < 1e-5 and e["max_abs_x"] < 1e-5     # north_star: 1e-5 fp32 per step
+    e = pc.ddpm_chain_case(F32, steps=50, oracle_dev=False)                      # (fp32 bound: against the oracle on the HOST;
+    assert e["finite"] and e["max_abs_eps"] < 1e-5 and e["max_abs_x"] < 1e-5     # north_star: 1e-5 fp32 per step   the 16-bit
+    #                                                                              runs below evaluate it with torch on the device)
     # bf16 operands: eps carries ~1.5e-2 (8 mantissa bits through 12 layers); with the 50-step schedule eps enters
     # x_{t-1} with a coefficient of up to ~0.3, with the sampling schedule (1000 steps, sample.py:144) ~0.007-0.02
     e = pc.ddpm_chain_case(BF16, steps=50)

@@ -156,7 +156,7 @@ def _rank_main(rank, world, port, B, S, E, noise_mode, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,noise_mode", [(2, "device"), (2, "reference"), (4, "device")])
+@pytest.mark.parametrize("world,noise_mode", [(2, "device"), pytest.param(2, "reference", marks=pytest.mark.slow), (4, "device")])
 def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
     """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with an UNEVEN split --
     B = 3 samples: world 2 -> shards of 2 and 1, world 4 -> one rank owns nothing -- equals the single-process cascade

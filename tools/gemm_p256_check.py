@@ -12,7 +12,7 @@ import torch
 
 from brepgen_amd import _lib, ops
 
-MS = [int(v) for v in sys.argv[1:]] or [17280, 30720, 138752]
+MS = [int(v) for v in sys.argv[1:]] or [8640, 17280, 30720, 61440, 138752]
 lib = _lib.load()
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
@@ -53,13 +53,13 @@ def timed(fn, n=20):
 
 bad = 0
 for dt in (torch.bfloat16, torch.float16):
-    for M in (1037, 256 * 7, 129, 4999, 17293):
+    for M in (1037, 256 * 7, 129, 4999, 17293, 8640, 30720 + 77):
         for k, (fn, N, K) in build(M, dt).items():
             lib.bg_tune_set(10, 2)
             ref = fn().clone()
             res = []
-            for al, nar in ((0, 0), (2, 0), (0, 1), (2, 1)):
-                setv(1, al, 7, 0, nar)
+            for mode, al, nar in ((1, 0, 0), (1, 2, 1), (0, 0, 0), (0, 0, 1)):
+                setv(mode, al, 0, 0, nar)
                 for rep in range(2):                                  # repeated: a race would not necessarily show the first time
                     got = fn()
                     torch.cuda.synchronize()
@@ -70,10 +70,8 @@ for dt in (torch.bfloat16, torch.float16):
                 nd = (ref != got).sum().item()
                 print(f"bit-equal {str(dt)[6:]:9s} M={M:5d} {k:12s} {ok} {res if not ok else ''} {'differing elements: %d' % nd if not ok else ''}")
 print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
-# (name, mode (key 10), align (key 9: 2 = staggered groups), start stagger (key 12: units + 1; 1 = off), nt stores (13), narrow passes (14))
-dt = torch.bfloat16
-VARS = [("128", 2, 0, 0, 0, 0), ("256 nostag", 1, 0, 1, 0, 0), ("256 stag4", 1, 0, 5, 0, 0), ("256 stag6", 1, 0, 7, 0, 0), ("256 stag10", 1, 0, 11, 0, 0),
-        ("256 stag6 nt", 1, 0, 7, 1, 0), ("256 stag6 narrow", 1, 0, 7, 0, 1), ("256 stag6 grp-lag", 1, 2, 7, 0, 0)]
+# (name, mode (key 10: 0 = hybrid 256 + 128, 1 = 256 alone, 2 = 128 alone), align (key 9: 2 = staggered wave groups), start stagger (12), nt (13), narrow (14))
+VARS = [("128", 2, 0, 0, 0, 0), ("256", 1, 0, 0, 0, 0), ("hybrid", 0, 0, 0, 0, 0)]
 for M in MS:
     cases = build(M, dt)
     res = {(k, v[0]): [] for k in cases for v in VARS}
