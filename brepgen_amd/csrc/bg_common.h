@@ -106,6 +106,7 @@ struct GemmArgs {
     // colsum[n] = sum_k w[n,k];  out = act(rstd_m * acc - mean_m * rstd_m * colsum[n] + bias[n]) with the row
     // statistics summed from stats_in [K/64][M][2].
     const float* stats_in = nullptr; const float* colsum = nullptr; float ln_eps = 1e-5f;
+    float* ln_coef = nullptr;         // scratch [M + 2][2]: per-row (rstd, -mean * rstd) for the 256 x 256 kernel's fold (gemm_p256.hip)
     // fp32 operands, M <= 8: allow the wave-per-column GEMV (tree reduction over K instead of the MFMA's k-ordered fma
     // chain -- last-bit different, so only callers whose M never depends on the batch composition set it: the
     // time-embedding MLP)
@@ -135,13 +136,23 @@ struct GemmArgs {
 // fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
 // times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
 constexpr int P256_TAIL_MIN = 160;
-__host__ __device__ inline int p256_rows(int rows, int nt_n256) {
+__host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false) {
     const int panels = (rows + 255) >> 8, T = panels * nt_n256;
+    if (split) {
+        // split-residual epilogue (out-proj / FFN2): a 256 x 256 tile spends as long in its epilogue (512 KiB of residual traffic,
+        // nothing to hide it behind) as in its K loop, so a full round is only ~10 % ahead of the 128 x 128 kernel and a launch seam
+        // costs more than that.  Measured (profiles/r03/gemm_p256_split_safe.log): it pays for one well-filled round (the compacted
+        // face batch: 204 tiles) and from ~4 rounds on (the edge nets); in between the 128 x 128 kernel runs alone.
+        if (T <= 256) return T >= 200 ? panels << 8 : 0;
+        if (T < 1024) return 0;
+        const int R = T >> 8, rem = T - (R << 8);
+        if (rem == 0 || rem >= 200) return panels << 8;
+        return ((R << 8) / nt_n256) << 8;
+    }
     const int R = T >> 8, rem = T - (R << 8);
     if (rem == 0 || rem >= P256_TAIL_MIN) return panels << 8;
     return ((R << 8) / nt_n256) << 8;
 }
-
 // 4 x 16-bit (bf16 | fp16) payload <-> floats
 template <bool F16> __device__ __forceinline__ void unpack4_16(uint2 u, float (&f)[4]) {
     if (F16) {

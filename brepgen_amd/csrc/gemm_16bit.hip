@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int G = gridDim.x;
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
-    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
+    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, SPLIT) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
     // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
     // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
     // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
@@ -835,12 +835,16 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
             ProfScope prof(PK_GEMM_P256, fl, by, s);
             return launch_p256<F16>(g, s);
         }
-        const int rows_hi = p256_rows(g.M, g.N_pad / 256);        // upper bound of what the 256 kernel may own
+        const bool split = g.out_lo != nullptr;
+        // upper bound of what the 256 kernel may own (a device-side row count can only be smaller: the split rule is not monotonic,
+        // so with one the launch happens whenever ANY row count up to the bound could give it rows)
+        int rows_hi = p256_rows(g.M, g.N_pad / 256, split);
+        if (split && g.m_dev != nullptr && rows_hi == 0 && ((g.M + 255) / 256) * (g.N_pad / 256) >= 200) rows_hi = 256;
         const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK);
         if (rows_hi > 0 && can_tail) {
             GemmArgs h = g;
             h.hybrid = 1;
-            const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256), rows_all);
+            const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split), rows_all);
             rows_tail = rows_all - rows_p;
             gemm_cost(g, rows_p, fl, by);
             int rc;

@@ -55,11 +55,12 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-template <bool F16, int MODE, bool NARROW>
+template <bool F16, int MODE, bool NARROW, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_epilogue, int stagger_units, int nt_stores) {
-    constexpr bool FOLD = MODE == P_FOLD16;
-    static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16, "16-bit output epilogues only");
-    static_assert(NARROW || !FOLD, "the LayerNorm-fold epilogue is written for 32-column passes");
+    constexpr bool FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
+    static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16 || MODE == P_SPLIT, "16-bit output epilogues only");
+    static_assert(NARROW == FOLD || MODE == P_PLAIN16, "the LayerNorm-fold epilogue is written for 32-column passes");
+    static_assert(SPLIT || !STATS, "row statistics are an output of the split-residual epilogue");
     using E = Elem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     const int nt_n = g.N_pad >> 8;
     // (hybrid launches: only the row panels that fill complete rounds -- the 128 x 128 kernel runs the rest, bg_common.h)
-    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n) >> 8) : ((Mv + 255) >> 8)) * nt_n;
+    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n, SPLIT) >> 8) : ((Mv + 255) >> 8)) * nt_n;
     const int G = gridDim.x;
     // XCD-aware walk: workgroup b (on XCD b % 8) owns tiles first, first + G, ... of the row-major tile list, `first` being
     // consecutive for the workgroups of one XCD -- the ~32 tiles an XCD runs at a time cover 3-4 row panels x all column tiles, so
@@ -152,53 +153,17 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
             dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), (unsigned)ln * 16u);
         }
     };
-    // LayerNorm fold: (rstd, -mean * rstd) of the wave's 128 rows of a tile.  The lower half wave works out row tiles 0, 1, the
-    // upper half 2, 3 (row tile i -> row m0 + wm*128 + 32 i + l31), each from the row's 12 partial (sum, sum of squares) pairs in
-    // the association order every kernel uses (tree16).  Load and use are separate calls so that the epilogue can put its own
-    // work in between.
-    // The row statistics are loaded by inline asm: hipcc's own bookkeeping ignores the younger stores when it waits for a load (it
-    // would wait for vmcnt(0), i.e. until every store of this epilogue has been acknowledged); here the loads are issued ahead of
-    // the epilogue's 16 stores and waited for with the exact count behind them.  Both row tiles of the half wave: 24 loads of 8 B.
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    struct RowStats { f32x2 v[2][FOLD_PARTS]; };
-    auto stats_issue = [&](int m0t, RowStats& r, int ii) {
-        const int ln = opaque(threadIdx.x & 63);
-        {
-            int grow = m0t + wm * 128 + (2 * (ln >> 5) + ii) * 32 + (ln & 31);
-            grow = grow < Mv ? grow : Mv - 1;
-            const unsigned voff = (unsigned)grow * 8u;            // part-major [K/64][M] pairs: part p at + p * M * 8 bytes
-#pragma unroll
-            for (int p = 0; p < FOLD_PARTS; ++p) {
-                const unsigned char* base = reinterpret_cast<const unsigned char*>(g.stats_in) + (size_t)p * g.M * 8;
-                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r.v[ii][p]) : "v"(voff), "s"(base) : "memory");
-            }
-        }
-    };
-    // YOUNGER = number of vector-memory instructions issued since stats_issue (they retire in order)
-    auto stats_wait = [&](RowStats& r, auto younger_c) {
-        constexpr int YOUNGER = decltype(younger_c)::value;
-        asm volatile("s_waitcnt vmcnt(%12)"
-                     : "+v"(r.v[0][0]), "+v"(r.v[0][1]), "+v"(r.v[0][2]), "+v"(r.v[0][3]), "+v"(r.v[0][4]), "+v"(r.v[0][5]),
-                       "+v"(r.v[0][6]), "+v"(r.v[0][7]), "+v"(r.v[0][8]), "+v"(r.v[0][9]), "+v"(r.v[0][10]), "+v"(r.v[0][11])
-                     : "n"(YOUNGER) : "memory");
-        asm volatile(""
-                     : "+v"(r.v[1][0]), "+v"(r.v[1][1]), "+v"(r.v[1][2]), "+v"(r.v[1][3]), "+v"(r.v[1][4]), "+v"(r.v[1][5]),
-                       "+v"(r.v[1][6]), "+v"(r.v[1][7]), "+v"(r.v[1][8]), "+v"(r.v[1][9]), "+v"(r.v[1][10]), "+v"(r.v[1][11])
-                     :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto stats_coeffs = [&](const RowStats& r) {                  // -> the coefficient slots of the patch
-        const int ln = opaque(threadIdx.x & 63);
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            float ps[16], pq[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                ps[p] = p < FOLD_PARTS ? r.v[ii][p < FOLD_PARTS ? p : 0][0] : 0.f;
-                pq[p] = p < FOLD_PARTS ? r.v[ii][p < FOLD_PARTS ? p : 0][1] : 0.f;
-            }
-            reinterpret_cast<float2*>(patch + 2560)[(2 * (ln >> 5) + ii) * 32 + (ln & 31)] =
-                ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+    // LayerNorm fold: the (rstd, -mean * rstd) pairs of the wave's 128 rows come from g.ln_coef (one pair per row, written by
+    // ln_coef_kernel ahead of this launch) as one 1 KiB LDS-DMA piece, like the column vectors.  (The row statistics themselves
+    // -- 12 partial pairs per row -- cannot be summed here without cost: loads issued from the epilogue share the vector-memory
+    // counter with its stores, and the two classes retire out of order, so waiting for such a load means waiting for the stores.)
+    auto stage_rows = [&](int m0t) {
+        if (FOLD) {
+            const int ln = opaque(threadIdx.x & 63);
+            int pair = ((m0t + wm * 128) >> 1) + ln;              // 16 bytes = the pairs of two rows
+            const int last = (Mv - 1) >> 1;                       // (rows past the end: any valid address, the result is never stored)
+            pair = pair < last ? pair : last;
+            dma(patch_lds + 2560u, reinterpret_cast<const unsigned char*>(g.ln_coef), (unsigned)pair * 16u);
         }
     };
 
@@ -252,15 +217,8 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     const unsigned char* a_cur = Ab + (size_t)m0 * lda_b;
     const unsigned char* w_cur = Wb + (size_t)n0 * ldw_b;
     a_offsets(m0);
-    if (FOLD) {
-        RowStats r;
-        stats_issue(m0, r, 0);
-        stats_issue(m0, r, 1);
-        stats_wait(r, std::integral_constant<int, 0>{});
-        stats_coeffs(r);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     stage_cols(n0);
+    stage_rows(m0);
 
     // ---- prologue: buffer 0 complete, the two A halves of buffer 1 in flight (as if issued in phases 7, 8) ----
     stage(0, 0, a_cur, ha[0]); stage(0, 1, a_cur, ha[1]); stage(0, 2, w_cur, hw); stage(0, 3, w_cur + w_half, hw);
@@ -333,15 +291,13 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
             const int rbase = m0 + wm * 128, cbase = n0 + wn * 64;
             T* out = reinterpret_cast<T*>(g.out);
             typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-            // Unconditional: a row past the end computed on a copy of row Mv - 1 (the A rows are clamped, so are its LayerNorm
-            // statistics) and holds that row's exact values -- it is stored over row Mv - 1 again.  Every tile thus issues the same
-            // number of stores, which the counted wait of the LayerNorm-fold epilogue relies on.
             auto store16 = [&](int grow, int col, uint4 v) {
-                grow = grow < Mv ? grow : Mv - 1;
-                u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
-                const u32x4 vv = {v.x, v.y, v.z, v.w};
-                if (nt_stores) __builtin_nontemporal_store(vv, dst);
-                else *dst = vv;
+                if (grow < Mv) {
+                    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
+                    const u32x4 vv = {v.x, v.y, v.z, v.w};
+                    if (nt_stores & 1) __builtin_nontemporal_store(vv, dst);
+                    else *dst = vv;
+                }
             };
             // one accumulator quad (row l31 of row tile i, columns j*32 + 8 q + 4 hq .. +3) -> 4 x 16 bit
             auto quad = [&](int i, int j, int q, float4 b, float4 c, float2 cf) -> uint2 {
@@ -358,7 +314,118 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                 return pk.u;
             };
             const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (!NARROW) {
+            if constexpr (SPLIT) {
+                // Split residual stream (out-proj / FFN2): x_new = acc + bias + (hi + lo) -> (hi, lo) planes + per-64-column row
+                // statistics, in place.  The wave's 128 x 64 block goes through the 4 KiB patch in eight slabs of 16 rows x 64 fp32
+                // columns (row tile t >> 1, rows 16 (t & 1) ..): the 32 lanes that own those rows write their eight quads; on the
+                // way back a lane owns 8 consecutive columns of a row, so the residual arrives and hi / lo leave as 16-byte
+                // accesses of whole 128-byte lines, and one 8-lane butterfly gives the row's (sum, sum of squares) -- the
+                // arithmetic, its order and the statistics layout of the 128 x 128 kernel (gemm_16bit.hip), bit for bit.
+                // The residual loads are inline asm and waited for with vmcnt(0) BEFORE the first store that follows them: the
+                // vector-memory counter is shared by loads and stores and the two classes retire out of order with respect to each
+                // other (a counted wait with younger stores passed early under load: measured, profiles/r03/gemm_p256_split_*.log),
+                // so a wave can only wait for a load issued after a store by waiting for that store as well.  Hence three batches
+                // (slabs 0-2, 3-5, 6-7: 48 registers in flight, the most that fits beside the accumulators without spilling) --
+                // three exposed waits per tile instead of one per slab.
+                const int k8 = ln & 7, r8 = ln >> 3;
+                float4 bias0 = zero4, bias1 = zero4;
+                if (has_bias) {
+                    bias0 = *reinterpret_cast<const float4*>(patch + (unsigned)(wn * 64 + k8 * 8) * 4u);
+                    bias1 = *reinterpret_cast<const float4*>(patch + (unsigned)(wn * 64 + k8 * 8 + 4) * 4u);
+                }
+                const unsigned char* rh = reinterpret_cast<const unsigned char*>(g.res_hi);
+                const unsigned char* rl = reinterpret_cast<const unsigned char*>(g.res_lo);
+                const unsigned col_b = (unsigned)(cbase + k8 * 8) * 2u;
+                u32x4 rbuf[8][2][2];                                  // [slab][it][hi / lo]; at most 3 slabs are live at a time (2 ahead)
+                auto res_issue = [&](int t) {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        int grow = rbase + t * 16 + it * 8 + r8;
+                        grow = grow < Mv ? grow : Mv - 1;
+                        const unsigned voff = (unsigned)grow * (unsigned)g.ld_res * 2u + col_b;
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbuf[t][it][0]) : "v"(voff), "s"(rh) : "memory");
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbuf[t][it][1]) : "v"(voff), "s"(rl) : "memory");
+                    }
+                };
+                auto res_wait = [&](int t0, int t1) {                // every load issued so far has landed (slabs t0 .. t1 - 1)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int t = t0; t < t1; ++t)                     // (pins the destination registers behind the wait)
+                        asm volatile("" : "+v"(rbuf[t][0][0]), "+v"(rbuf[t][0][1]), "+v"(rbuf[t][1][0]), "+v"(rbuf[t][1][1]) :: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                T* out_lo = reinterpret_cast<T*>(g.out_lo);
+                // patch rows of 256 B; 16-byte chunk c XOR-swizzled by the row: ds_write_b128 and ds_read_b128 conflict-free
+                auto slab = [&](int t) {
+                    const int i = t >> 1, half = t & 1;
+                    if ((l31 >> 4) == half) {
+                        const int prow = l31 & 15;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c16 = j * 8 + 2 * q + hq;
+                                *reinterpret_cast<float4*>(patch + prow * 256 + ((c16 ^ prow) << 4)) =
+                                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                            }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int prow = it * 8 + r8;
+                        const float4 p0 = *reinterpret_cast<const float4*>(patch + prow * 256 + (((2 * k8) ^ prow) << 4));
+                        const float4 p1 = *reinterpret_cast<const float4*>(patch + prow * 256 + (((2 * k8 + 1) ^ prow) << 4));
+                        float v[8] = {p0.x + bias0.x, p0.y + bias0.y, p0.z + bias0.z, p0.w + bias0.w,
+                                      p1.x + bias1.x, p1.y + bias1.y, p1.z + bias1.z, p1.w + bias1.w};
+                        if (g.act == BG_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        const u32x4 h4 = rbuf[t][it][0], l4 = rbuf[t][it][1];
+                        float fh[4], fl[4];
+                        unpack4_16<F16>(make_uint2(h4[0], h4[1]), fh);
+                        unpack4_16<F16>(make_uint2(l4[0], l4[1]), fl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += fh[e] + fl[e];
+                        unpack4_16<F16>(make_uint2(h4[2], h4[3]), fh);
+                        unpack4_16<F16>(make_uint2(l4[2], l4[3]), fl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 + e] += fh[e] + fl[e];
+                        const int grow = rbase + t * 16 + prow;
+                        const bool row_ok = grow < Mv;                // (in place: a clamped duplicate row must not be written)
+                        if (STATS) {
+                            const float s8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                            const float q8 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
+                                             ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                            const float S = group8_sum(s8), Q = group8_sum(q8);
+                            if (row_ok && k8 == 0)
+                                reinterpret_cast<float2*>(g.stats_out)[(size_t)(cbase / 64) * g.M + grow] = make_float2(S, Q);
+                        }
+                        if (row_ok) {
+                            const float va[4] = {v[0], v[1], v[2], v[3]}, vb[4] = {v[4], v[5], v[6], v[7]};
+                            uint2 ha, la, hb, lb;
+                            split4_16<F16>(va, ha, la);
+                            split4_16<F16>(vb, hb, lb);
+                            const size_t o = (size_t)grow * g.ldc + cbase + k8 * 8;
+                            *reinterpret_cast<uint4*>(out + o) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+                            *reinterpret_cast<uint4*>(out_lo + o) = make_uint4(la.x, la.y, lb.x, lb.y);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                res_issue(0); res_issue(1); res_issue(2);
+                res_wait(0, 3);
+                slab(0); slab(1); slab(2);
+                __builtin_amdgcn_sched_barrier(0);
+                res_issue(3); res_issue(4); res_issue(5);
+                res_wait(3, 6);
+                slab(3); slab(4); slab(5);
+                __builtin_amdgcn_sched_barrier(0);
+                res_issue(6); res_issue(7);
+                res_wait(6, 8);
+                slab(6); slab(7);
+            } else if constexpr (!NARROW) {
                 // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias
                 float4 bz[2][4];
 #pragma unroll
@@ -414,24 +481,13 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                     }
                     __builtin_amdgcn_wave_barrier();
                 };
-                // The next tile's row statistics are requested ahead of the passes (second row tile: once half of the accumulators
-                // are free) and turned into coefficients behind them -- exactly 8 stores younger than the last load: their
-                // latency hides behind this epilogue's own work.  Unconditional: without a next tile the clamped rows are loaded
-                // and the results never read.
-                RowStats rs;
-                if (FOLD) stats_issue(m0n, rs, 0);
-                __builtin_amdgcn_sched_barrier(0);
                 pass(0, 0); pass(0, 1); pass(1, 0); pass(1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (FOLD) stats_issue(m0n, rs, 1);
-                __builtin_amdgcn_sched_barrier(0);
                 pass(2, 0); pass(2, 1); pass(3, 0); pass(3, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (FOLD) { stats_wait(rs, std::integral_constant<int, 8>{}); stats_coeffs(rs); }
             }
             if (has_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the patch accesses above are complete
                 stage_cols(n0n);
+                stage_rows(m0n);
             }
         }
         if (!has_next) break;
@@ -441,26 +497,55 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     if (!align_epilogue && wm == 0) bar();                        // pairs with the extra barrier of waves 4-7
 }
 
+// (sum, sum of squares) partials per 64-column group [K/64][M][2] -> (rstd, -mean * rstd) per row [M][2], in the association order
+// every kernel uses (tree16 + ln_fold_coeffs): what the LayerNorm-fold epilogue of the 256 x 256 kernel reads.  One thread per row.
+__global__ __launch_bounds__(256) void ln_coef_kernel(const float2* __restrict__ stats, float2* __restrict__ coef, int M,
+                                                       const int* __restrict__ m_dev, int K, float eps) {
+    const int Mv = m_dev ? *m_dev : M;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= Mv) return;
+    float ps[16], pq[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const float2 v = p < FOLD_PARTS ? stats[(size_t)p * M + row] : make_float2(0.f, 0.f);
+        ps[p] = v.x; pq[p] = v.y;
+    }
+    coef[row] = ln_fold_coeffs(tree16(ps), tree16(pq), K, eps);
+}
+
 bool p256_eligible(const GemmArgs& g) {
-    const bool fold = g.stats_in != nullptr;
-    return g.N_pad % 256 == 0 && g.N == g.N_pad && g.K % (2 * G_BK) == 0 && g.K >= 2 * G_BK && g.ldc % 8 == 0 &&
-           g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.out_lo == nullptr && g.res_hi == nullptr &&
-           g.stats_out == nullptr && g.row_map == nullptr && g.cv_C == 0 &&
-           (!fold || (g.K == FOLD_PARTS * G_BK && g.colsum != nullptr && g.bias != nullptr)) &&
-           (size_t)255 * g.lda * 2 + 128 < 0xffffffffull && (size_t)255 * g.K * 2 + 128 < 0xffffffffull;
+    const bool fold = g.stats_in != nullptr, split = g.out_lo != nullptr;
+    if (!(g.N_pad % 256 == 0 && g.N == g.N_pad && g.K % (2 * G_BK) == 0 && g.K >= 2 * G_BK && g.ldc % 8 == 0 &&
+          g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.row_map == nullptr && g.cv_C == 0 &&
+          (size_t)255 * g.lda * 2 + 128 < 0xffffffffull && (size_t)255 * g.K * 2 + 128 < 0xffffffffull))
+        return false;
+    if (split)          // split residual stream in place (out-proj / FFN2): residual planes required, no LayerNorm fold on top
+        return !fold && g.res_hi != nullptr && g.res_lo != nullptr && g.ld_res % 8 == 0 && (size_t)g.M * g.ld_res * 2 < 0xffffffffull;
+    return g.res_hi == nullptr && g.stats_out == nullptr &&
+           (!fold || (g.K == FOLD_PARTS * G_BK && g.colsum != nullptr && g.bias != nullptr && g.ln_coef != nullptr));
 }
 
 template <bool F16>
 int launch_p256(const GemmArgs& g, hipStream_t s) {
-    const int tiles = ((g.hybrid ? p256_rows(g.M, g.N_pad / 256) : g.M + 255) / 256) * (g.N_pad / 256);   // upper bound (varlen: g.M)
+    // tiles this launch may own: host-side row count -> the hybrid rule; device-side row count -> every tile of the bound (the rule
+    // is evaluated on the device, surplus workgroups exit at once)
+    const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr) : g.M + 255) / 256) * (g.N_pad / 256);
     if (tiles == 0) return 0;
     const int grid = tiles < 256 ? tiles : 256;
+    if (g.stats_in) {                                             // LayerNorm fold: one (rstd, -mean rstd) pair per row first
+        hipLaunchKernelGGL(ln_coef_kernel, dim3((g.M + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2*>(g.stats_in),
+                           reinterpret_cast<float2*>(g.ln_coef), g.M, g.m_dev, g.K, g.ln_eps);
+        const int rc = launch_status("ln_coef");
+        if (rc) return rc;
+    }
     const int align = g_tune[TUNE_P256_ALIGN] != 2;               // bg_tune key 9: 2 = wave groups enter the epilogue one barrier apart
     // start stagger (see the kernel; bg_tune key 12 = units + 1): measured a loss at every setting (profiles/r03/
     // gemm_p256_knob_sweep.log: lock-step workgroups share their A / W fetches in the L2), so it is off unless asked for
     const int stg = g_tune[TUNE_P256_STAGGER] > 1 && tiles >= 2 * 256 - 64 ? g_tune[TUNE_P256_STAGGER] - 1 : 0;
-    const int nt = g_tune[TUNE_P256_NT];
-    if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    const int nt = g_tune[TUNE_P256_NT];                          // bit 0: non-temporal output stores, bit 1: vmcnt(0) waits in the split epilogue
+    if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else if (g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     return launch_status("gemm16_p256");

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""In-process A/B of bg_tune settings on the three face-LDM loops of bench.py (one box, one process, interleaved rounds):
+    python tools/face_ldm_ab.py "10=2" "10=0" "10=0,11=480" ...        each argument = one setting (key=value,...)"""
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+from brepgen_amd import _lib
+
+SETTINGS = sys.argv[1:] or ["10=2", "10=0"]
+KEYS = sorted({int(kv.split("=")[0]) for s in SETTINGS for kv in s.split(",") if kv})
+lib = _lib.load()
+dev = torch.device("cuda")
+ldm = bench.FaceLDM(dev, 0)
+STEPS, ROUNDS = 20, 3
+
+
+def apply(setting):
+    for k in KEYS:
+        lib.bg_tune_set(k, 0)
+    for kv in filter(None, setting.split(",")):
+        k, v = kv.split("=")
+        lib.bg_tune_set(int(k), int(v))
+
+
+def clock(ks):
+    ldm.run(*[1 if k else 0 for k in ks])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ldm.run(*ks)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / sum(ks) * 1e3
+
+
+for split in (1, 2):
+    ldm.set_split(split)
+    res = {(s, leg): [] for s in SETTINGS for leg in "ABC"}
+    for r in range(ROUNDS):
+        for s in SETTINGS:
+            apply(s)
+            for leg, ks in zip("ABC", ((STEPS, 0, 0), (0, STEPS, 0), (0, 0, STEPS))):
+                res[(s, leg)].append(clock(ks))
+    print(f"n_split = {split}   (ms per step, median of {ROUNDS} rounds x {STEPS} steps; composite = (158 A + 250 B + 209 C) / 617)")
+    for s in SETTINGS:
+        m = {leg: statistics.median(res[(s, leg)]) for leg in "ABC"}
+        comp = (158 * m["A"] + 250 * m["B"] + 209 * m["C"]) / 617
+        print(f"  {s:24s} A {m['A']:.3f}  B {m['B']:.3f}  C {m['C']:.3f}  composite {comp:.3f}")
+apply("")

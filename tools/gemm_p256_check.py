@@ -23,6 +23,9 @@ def setv(mode, al, stg, nt, nar):
     lib.bg_tune_set(10, mode); lib.bg_tune_set(9, al); lib.bg_tune_set(12, stg); lib.bg_tune_set(13, nt); lib.bg_tune_set(14, nar)
 
 
+TIMING = False
+
+
 def build(M, dt):
     x = rn(M, 768) * 2
     hi = x.to(dt).to(dev)
@@ -36,6 +39,18 @@ def build(M, dt):
         cases[name + " plain"] = (lambda a=a, w=w, b=b, act=act: ops.linear(a, w, b, out_dtype=dt, act=act), N, K)
         cases[name + " nobias"] = (lambda a=a, w=w: ops.linear(a, w, None, out_dtype=dt), N, K)
         cases[name + " fold"] = (lambda a=a, w=w, b=b, act=act, cs=cs: ops.linear_ex(a, w, b, act=act, stats_in=stats, colsum=cs)["out"], N, K)
+    lo = (x - x.to(dt).float()).to(dt).to(dev)
+    a1024 = (rn(M, 1024) * 0.5).to(dt).to(dev)
+    for name, N, K, a in (("outproj", 768, 768, hi), ("ffn2", 768, 1024, a1024)):
+        w, b = (rn(N, K) * 0.04).to(dt).to(dev), rn(N).to(dev)
+
+        def split(a=a, w=w, b=b, st=True):
+            r = ops.linear_ex(a, w, b, split_out=True, res=(hi, lo), want_stats=st)
+            if TIMING:
+                return r["out"]
+            return torch.cat([r["out"].float().flatten(), r["lo"].float().flatten()] + ([r["stats"].flatten()] if st else []))
+        cases[name + " split"] = (split, N, K)
+        cases[name + " split-ns"] = (lambda f=split: f(st=False), N, K)
     return cases
 
 
@@ -53,13 +68,13 @@ def timed(fn, n=20):
 
 bad = 0
 for dt in (torch.bfloat16, torch.float16):
-    for M in (1037, 256 * 7, 129, 4999, 17293, 8640, 30720 + 77):
+    for M in (1037, 256 * 7, 4999, 17293, 30720 + 77):
         for k, (fn, N, K) in build(M, dt).items():
             lib.bg_tune_set(10, 2)
             ref = fn().clone()
             res = []
-            for mode, al, nar in ((1, 0, 0), (1, 2, 1), (0, 0, 0), (0, 0, 1)):
-                setv(mode, al, 0, 0, nar)
+            for mode, al, nar, nt in ((1, 0, 0, 0), (1, 2, 1, 0), (0, 0, 0, 0), (0, 0, 1, 0)):
+                setv(mode, al, 0, nt, nar)
                 for rep in range(2):                                  # repeated: a race would not necessarily show the first time
                     got = fn()
                     torch.cuda.synchronize()
@@ -70,6 +85,7 @@ for dt in (torch.bfloat16, torch.float16):
                 nd = (ref != got).sum().item()
                 print(f"bit-equal {str(dt)[6:]:9s} M={M:5d} {k:12s} {ok} {res if not ok else ''} {'differing elements: %d' % nd if not ok else ''}")
 print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
+TIMING = True
 # (name, mode (key 10: 0 = hybrid 256 + 128, 1 = 256 alone, 2 = 128 alone), align (key 9: 2 = staggered wave groups), start stagger (12), nt (13), narrow (14))
 VARS = [("128", 2, 0, 0, 0, 0), ("256", 1, 0, 0, 0, 0), ("hybrid", 0, 0, 0, 0, 0)]
 for M in MS:
