@@ -128,7 +128,8 @@ struct GemmArgs {
     const void* cv_zero = nullptr;
     // ---- 256 + 128 hybrid (set by the launcher only): rows [0, p256_rows(*m_dev, N_pad / 256)) belong to the 256 x 256 kernel,
     // the rest to the 128 x 128 kernel -- both evaluate the same rule on the device-side row count ----
-    int hybrid = 0;
+    int hybrid = 0;                   // 1: the split above; 2: all-or-nothing (concurrent sample groups, see p256_rows)
+    int concurrent = 0;               // caller's hint: other launches of the same kind are in flight on sibling streams
 };
 
 // Tile-round quantisation: one 256 x 256 tile per CU and round, so a launch whose tile count is a little
@@ -136,8 +137,15 @@ struct GemmArgs {
 // fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
 // times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
 constexpr int P256_TAIL_MIN = 160;
-__host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false) {
+__host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false, bool all_or_nothing = false) {
     const int panels = (rows + 255) >> 8, T = panels * nt_n256;
+    if (all_or_nothing) {
+        // Several sample groups in flight on forked streams (n_split > 1): a partial round of one group's launch is filled by the
+        // other group's, and a tail kernel only adds a dependent launch to each chain -- the 256 kernel runs alone or not at all
+        // (measured, profiles/r03/face_ldm_legs_ab_p256.log: leg B 4.17 vs 4.41 ms with the tail kernels)
+        if (split) return (T >= 1024 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
+        return (T >= 400 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
+    }
     if (split) {
         // split-residual epilogue (out-proj / FFN2): a 256 x 256 tile spends as long in its epilogue (512 KiB of residual traffic,
         // nothing to hide it behind) as in its K loop, so a full round is only ~10 % ahead of the 128 x 128 kernel and a launch seam
@@ -153,6 +161,7 @@ __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = fal
     if (rem == 0 || rem >= P256_TAIL_MIN) return panels << 8;
     return ((R << 8) / nt_n256) << 8;
 }
+
 // 4 x 16-bit (bf16 | fp16) payload <-> floats
 template <bool F16> __device__ __forceinline__ void unpack4_16(uint2 u, float (&f)[4]) {
     if (F16) {

@@ -107,6 +107,7 @@ struct Ctx {
     const int* offsets = nullptr;     // per-sample first row, [B+1]
     int N_tok = 1;                    // tokens per sample of the padded layout
     double rows_hint = 0.0, pairs_hint = 0.0;
+    int concurrent = 0;               // sibling sample groups are in flight on forked streams (n_split > 1)
 };
 
 // Linear(k,768)+b -> LN -> SiLU -> Linear(768,n)+b (+adds) ; x fp32 rows (lda), or activations in compute dtype for fc_out
@@ -193,6 +194,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
     const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
     c.N_tok = N;
+    c.concurrent = in->n_split < 0;
     if (varlen) {
         int* offs = reinterpret_cast<int*>(c.ws + c.p.off_rows);
         int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2) * 4));
@@ -276,25 +278,25 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum; qkv.ln_coef = c.coef;
-        qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint;
+        qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
         if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
-        op.m_dev = c.m_dev; op.rows_hint = c.rows_hint;
+        op.m_dev = c.m_dev; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;
         if ((rc = gemm(op, c.dtype, s))) return rc;
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         f1.stats_in = c.stats; f1.colsum = L.w1_colsum; f1.ln_coef = c.coef;
-        f1.m_dev = c.m_dev; f1.rows_hint = c.rows_hint;
+        f1.m_dev = c.m_dev; f1.rows_hint = c.rows_hint; f1.concurrent = c.concurrent;
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         f2.out_lo = c.XL; f2.res_hi = c.XH; f2.res_lo = c.XL; f2.ld_res = 768; f2.stats_out = c.stats;
-        f2.m_dev = c.m_dev; f2.rows_hint = c.rows_hint;
+        f2.m_dev = c.m_dev; f2.rows_hint = c.rows_hint; f2.concurrent = c.concurrent;
         if ((rc = gemm(f2, c.dtype, s))) return rc;
     }
     for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
-        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rows_hint = c.rows_hint; };
+        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rows_hint = c.rows_hint; g.concurrent = c.concurrent; };
         if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         vl(qkv);
@@ -391,21 +393,30 @@ static size_t plan_total_split(int net, int B, int S, int E, int dtype, int n) {
     }
     return t;
 }
-// helper streams + fork / join events of the split mode: created once, used under a mutex (enqueue only: microseconds)
+// helper streams + fork / join events of the split mode: created once PER DEVICE (a process that drives nets on several devices
+// must not enqueue a sub-batch on another device's stream), used under a mutex (enqueue only: microseconds)
 struct SplitState {
     hipStream_t aux[MAX_SPLIT - 1];
     hipEvent_t fork, join[MAX_SPLIT - 1];
-    bool ok = false;
+    bool tried = false, ok = false;
 };
-static SplitState g_split;
-static std::once_flag g_split_once;
+constexpr int MAX_SPLIT_DEVICES = 64;
+static SplitState g_split_dev[MAX_SPLIT_DEVICES];
 static std::mutex g_split_mutex;
-static void split_init() {
-    bool ok = hipEventCreateWithFlags(&g_split.fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < MAX_SPLIT - 1 && ok; ++i)
-        ok = hipStreamCreateWithFlags(&g_split.aux[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&g_split.join[i], hipEventDisableTiming) == hipSuccess;
-    g_split.ok = ok;
+// (called with g_split_mutex held) -> the state of the CURRENT device, or nullptr
+static SplitState* split_state() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_SPLIT_DEVICES) return nullptr;
+    SplitState& st = g_split_dev[dev];
+    if (!st.tried) {
+        st.tried = true;
+        bool ok = hipEventCreateWithFlags(&st.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < MAX_SPLIT - 1 && ok; ++i)
+            ok = hipStreamCreateWithFlags(&st.aux[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&st.join[i], hipEventDisableTiming) == hipSuccess;
+        st.ok = ok;
+    }
+    return st.ok ? &st : nullptr;
 }
 }  // namespace bg
 
@@ -438,12 +449,13 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
     BG_REQUIRE(((uintptr_t)workspace & 255) == 0, BG_E_ALIGN, "bg_denoiser_fwd: workspace must be 256-byte aligned");
     BG_REQUIRE(workspace_bytes >= plan_total_split(net, in->B, S, E, w->dtype, ns), BG_E_WORKSPACE,
                "bg_denoiser_fwd: workspace too small for n_split = %d", ns);
-    std::call_once(g_split_once, split_init);
-    BG_REQUIRE(g_split.ok, BG_E_ARG, "bg_denoiser_fwd: could not create the helper streams of the split mode");
     static const int kInCols[4] = {6, 48, 6, 18};                 // channels of x per net (SurfPos, SurfZ, EdgePos, EdgeZ)
     const size_t tok = (size_t)S * E;
     const size_t mask_per_sample = (net == BG_EDGEZ) ? tok : (size_t)S;
     std::lock_guard<std::mutex> lock(g_split_mutex);
+    SplitState* sp = split_state();
+    BG_REQUIRE(sp != nullptr, BG_E_ARG, "bg_denoiser_fwd: could not create the helper streams of the split mode on this device");
+    SplitState& g_split = *sp;
     hipError_t he = hipEventRecord(g_split.fork, s);
     BG_REQUIRE(he == hipSuccess, (int)he, "bg_denoiser_fwd: hipEventRecord failed: %s", hipGetErrorString(he));
     unsigned char* wsp = reinterpret_cast<unsigned char*>(workspace);
@@ -453,7 +465,7 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
         split_range(in->B, ns, k, lo, hi);
         bg_denoiser_inputs sub = *in;
         sub.B = hi - lo;
-        sub.n_split = 0;
+        sub.n_split = -1;                                         // (a sub-run: tells run() that sibling groups are in flight)
         sub.x = in->x + (size_t)lo * tok * kInCols[net];
         if (in->surf_pos) sub.surf_pos = in->surf_pos + (size_t)lo * S * 6;
         if (in->surf_z) sub.surf_z = in->surf_z + (size_t)lo * S * 48;

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int G = gridDim.x;
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
-    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, SPLIT) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
+    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, SPLIT, g.hybrid == 2) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
     // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
     // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
     // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
@@ -838,13 +838,17 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         const bool split = g.out_lo != nullptr;
         // upper bound of what the 256 kernel may own (a device-side row count can only be smaller: the split rule is not monotonic,
         // so with one the launch happens whenever ANY row count up to the bound could give it rows)
-        int rows_hi = p256_rows(g.M, g.N_pad / 256, split);
-        if (split && g.m_dev != nullptr && rows_hi == 0 && ((g.M + 255) / 256) * (g.N_pad / 256) >= 200) rows_hi = 256;
+        const int hmode = g.concurrent ? 2 : 1;
+        // Host-side view of the row count: exact without m_dev; with a device-side count the caller's estimate (rows_hint: the
+        // drop-in modules count the valid tokens once per mask) or else the bound M.  It only chooses between "both kernels, the
+        // device evaluates the rule" and "the 128 kernel alone, no rule" -- either is correct for any actual row count.
+        const int rows_est = (g.m_dev != nullptr && g.rows_hint > 0) ? (int)fmin((double)g.M, g.rows_hint + 0.5) : g.M;
+        const int rows_hi = p256_rows(rows_est, g.N_pad / 256, split, hmode == 2);
         const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK);
         if (rows_hi > 0 && can_tail) {
             GemmArgs h = g;
-            h.hybrid = 1;
-            const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split), rows_all);
+            h.hybrid = hmode;
+            const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split, hmode == 2), rows_all);
             rows_tail = rows_all - rows_p;
             gemm_cost(g, rows_p, fl, by);
             int rc;
@@ -853,12 +857,12 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
                 rc = launch_p256<F16>(h, s);
             }
             if (rc) return rc;
-            if (g.m_dev == nullptr && rows_hi >= g.M) return 0;   // dense and everything fitted
+            if (g.m_dev == nullptr && rows_hi >= g.M) return 0;   // exact host-side row count and everything fitted
             tail_only = true;
         }
     }
     GemmArgs gt = g;
-    gt.hybrid = tail_only ? 1 : 0;
+    gt.hybrid = tail_only ? (g.concurrent ? 2 : 1) : 0;
     const GemmArgs& g_ = gt;
     double fl_t, by_t;
     gemm_cost(g, rows_tail, fl_t, by_t);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     const int nt_n = g.N_pad >> 8;
     // (hybrid launches: only the row panels that fill complete rounds -- the 128 x 128 kernel runs the rest, bg_common.h)
-    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n, SPLIT) >> 8) : ((Mv + 255) >> 8)) * nt_n;
+    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n, SPLIT, g.hybrid == 2) >> 8) : ((Mv + 255) >> 8)) * nt_n;
     const int G = gridDim.x;
     // XCD-aware walk: workgroup b (on XCD b % 8) owns tiles first, first + G, ... of the row-major tile list, `first` being
     // consecutive for the workgroups of one XCD -- the ~32 tiles an XCD runs at a time cover 3-4 row panels x all column tiles, so
@@ -529,7 +529,7 @@ template <bool F16>
 int launch_p256(const GemmArgs& g, hipStream_t s) {
     // tiles this launch may own: host-side row count -> the hybrid rule; device-side row count -> every tile of the bound (the rule
     // is evaluated on the device, surplus workgroups exit at once)
-    const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr) : g.M + 255) / 256) * (g.N_pad / 256);
+    const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr, g.hybrid == 2) : g.M + 255) / 256) * (g.N_pad / 256);
     if (tiles == 0) return 0;
     const int grid = tiles < 256 ? tiles : 256;
     if (g.stats_in) {                                             // LayerNorm fold: one (rstd, -mean rstd) pair per row first

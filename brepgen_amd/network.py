@@ -104,6 +104,7 @@ class _HipDenoiser(nn.Module):
         # hide under the other's K loops: -7 % per step at batch 512 x 60).  "auto": 2 groups for batches of >= 16384
         # padded tokens, otherwise off.
         self.n_split = "auto"
+        self._hint_cache = {}
         self._packs = {}
         self._workspace = None
         self._cond = None                # conditioning-embed cache entry
@@ -232,6 +233,19 @@ class _HipDenoiser(nn.Module):
             class_label[uncond.to(class_label.device)] = 0
         return class_label.reshape(-1).to(device=device, dtype=torch.int64).contiguous()
 
+    def _row_hints(self, mask, S, E):
+        if self.profile_hints:
+            return self.profile_hints
+        if torch.cuda.is_current_stream_capturing():       # (a count needs a host synchronisation)
+            return 0.0, 0.0
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
+        if self._hint_cache.get("key") != key:
+            valid = (~mask.reshape(mask.shape[0], -1).bool()).sum(1).double()
+            if self.NET == BG_EDGEPOS:                     # the mask marks faces, every valid face carries E edge tokens
+                valid = valid * E
+            self._hint_cache = {"key": key, "hints": (float(valid.sum()), float((valid * valid).sum())), "keep": mask}
+        return self._hint_cache["hints"]
+
     def _run(self, x, timesteps, surf_pos, surf_z, edge_pos, mask, class_label, B, S, E, out_shape):
         if not x.is_cuda:
             raise _lib.BrepgenHipError("brepgen_amd denoisers run on the MI355X only (tensor on "
@@ -253,7 +267,9 @@ class _HipDenoiser(nn.Module):
         # step-invariant conditioning cache, keyed on the identity + version of the conditioning tensors
         inp.cond_cache, inp.cond_cache_valid = None, 0
         inp.varlen = int(bool(self.varlen) and mk is not None and self.NET != BG_SURFPOS)
-        inp.rows_hint, inp.pairs_hint = (self.profile_hints if (self.profile_hints and inp.varlen) else (0.0, 0.0))
+        # valid tokens / attention pairs of the batch: the host-side ESTIMATE the launcher uses to pick GEMM kernels (the device
+        # still counts the rows itself) and what the opt-in profiler books; counted once per mask tensor (identity + version)
+        inp.rows_hint, inp.pairs_hint = self._row_hints(mask, S, E) if inp.varlen else (0.0, 0.0)
         ns = self.n_split
         if ns == "auto":
             ns = 2 if (B >= 2 and B * S * E >= 16384) else 1

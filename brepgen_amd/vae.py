@@ -11,8 +11,8 @@ attention = one fused q|k|v GEMM + ``bg_small_attn`` + projection GEMM; ``Upsamp
 The nn.Module tree below only holds parameters.  Like the denoisers, bf16 operands inside autocast, exact fp32 outside.
 
 A pass is ONE C call: each module compiles itself (once per dtype) into a flat ``bg_vae_op`` program and ``bg_vae_run``
-enqueues every launch of it, chunking the batch against a caller-owned workspace (``executor = True``, the default).
-``executor = False`` drives the same primitives step by step from Python (the round-1 path, kept as the cross-check).
+enqueues every launch of it, chunking the batch against a caller-owned workspace.  (A step-by-step Python driver of the same
+primitives -- the round-1 path -- is kept as a cross-check in tests/vae_stepwise.py, outside the product module.)
 """
 import ctypes
 import math
@@ -237,16 +237,14 @@ class _Program:
 
 class _HipVAE(nn.Module):
     WS_BUDGET = 8 << 30            # bytes of bg_vae_run workspace (activation slots + scratch) per chunk of samples
-    IM2COL_BUDGET = 1 << 32        # bytes of im2col scratch per chunk of samples (288 GB of HBM: few, large chunks)
 
     def __init__(self):
         super().__init__()
         self.compute_dtype = None
-        # 16-bit modes: the 3x3 / k5 convolutions run as IMPLICIT GEMMs (bg_conv_gemm_fwd): GroupNorm + activation + cast in
-        # one elementwise pass, then the GEMM gathers the window itself -- the kh*kw-fold im2col matrix is never written.
-        # False = materialised im2col for every convolution (the round-1 path; also what fp32 and tiny batches use).
-        self.implicit_gemm = True
-        self.executor = True           # one bg_vae_run call per pass; False (or implicit_gemm False): step by step from Python
+        # 16-bit modes: the 3x3 / k5 convolutions run as IMPLICIT GEMMs inside bg_vae_run: GroupNorm + activation + cast in one
+        # elementwise pass, then the GEMM gathers the window itself -- the kh*kw-fold im2col matrix is never written (fp32 and
+        # tiny batches take the materialised im2col path, bit-identical).  The step-by-step Python driver of the same
+        # primitives that cross-checks the program lives in tests/vae_stepwise.py.
         self._packs = {}
         self._programs = {}
         self._zero = None
@@ -259,6 +257,10 @@ class _HipVAE(nn.Module):
     def load_state_dict(self, *a, **k):
         self._packs, self._programs = {}, {}
         return super().load_state_dict(*a, **k)
+
+    def release_workspace(self):
+        """Drop the cached bg_vae_run workspaces (up to WS_BUDGET bytes per (device, stream) this module has decoded on)."""
+        self._ws = {}
 
     def _zero_page(self, device):
         if self._zero is None or self._zero.device != device:
@@ -288,9 +290,6 @@ class _HipVAE(nn.Module):
         check(lib.bg_vae_run(pg.ops, len(pg.steps), pg.n_slots, h, w, c, ptr(x_cl), n, chunk, ptr(out),
                              ptr(self._zero_page(x_cl.device)), ptr(ws), ws.numel(), stream()), "bg_vae_run")
         return out
-
-    def _use_executor(self):
-        return self.executor and self.implicit_gemm
 
     def _dtype(self):
         if self.compute_dtype is not None:
@@ -326,70 +325,6 @@ class _HipVAE(nn.Module):
         return self._pack_gemm(w2, conv.bias, dt)
 
     # ---- primitive steps on channels-last fp32 tensors [S, H, W, C] ----
-    def _stats(self, x, S, P, C, norm):
-        st = torch.empty(S, norm.num_groups, 2, device=x.device, dtype=torch.float32)
-        check(_lib.load().bg_groupnorm_stats(ptr(x), ptr(st), S, P, C, norm.num_groups, norm.eps, stream()),
-              "bg_groupnorm_stats")
-        return st
-
-    def _conv(self, x, shape, pk, kh, kw, up=0, norm=None, act=ACT_NONE, residual=None, stride=1, pad=None):
-        """conv (kh x kw) on channels-last x; pad=None: 'same' (kh//2, kw//2); pad=(py, px): zeros before only."""
-        S, H, W, C = shape
-        lib = _lib.load()
-        Hl, Wl = H << up, W << up
-        if pad is None:
-            py, px = kh // 2, kw // 2
-            Ho, Wo = (Hl + 2 * py - kh) // stride + 1, (Wl + 2 * px - kw) // stride + 1
-        else:                                          # Downsample2D: F.pad(x, (0,1,0,1)) then stride-2 conv, no padding
-            py, px = pad
-            Ho, Wo = (Hl + 1 - kh) // stride + 1 if kh > 1 else Hl, (Wl + 1 - kw) // stride + 1
-        rows = S * Ho * Wo
-        st = self._stats(x, S, H * W, C, norm) if norm is not None else None
-        g = norm.weight.detach().float().contiguous() if norm is not None else None
-        b = norm.bias.detach().float().contiguous() if norm is not None else None
-        implicit = (self.implicit_gemm and pk.dtype != torch.float32 and kh * kw > 1 and stride == 1 and pad is None
-                    and C % 64 == 0 and _pow2(C // 64) and _pow2(Ho) and _pow2(Wo) and pk.n % 128 == 0
-                    and pk.w.shape[0] == pk.n and ((rows + 127) // 128) * (pk.n // 128) >= 64 and rows < 2 ** 31)
-        if implicit:
-            # normalise + activate + cast ONCE (a 1x1 "im2col"), then let the GEMM's loader walk the window
-            xn = torch.empty(S * H * W, C, device=x.device, dtype=pk.dtype)
-            check(lib.bg_im2col(ptr(x), ptr(xn), _CODE[pk.dtype], S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st), ptr(g), ptr(b),
-                                norm.num_groups if norm is not None else 1, act, None, stream()), "bg_im2col[norm+act+cast]")
-            out = torch.empty(rows, pk.n, device=x.device, dtype=torch.float32)
-            res = residual.contiguous() if residual is not None else None
-            d = _lib.ConvDesc()
-            d.x, d.S, d.H, d.W, d.C = ptr(xn), S, H, W, C
-            d.kh, d.kw, d.up = kh, kw, up
-            d.w, d.bias, d.N = ptr(pk.w), ptr(pk.b), pk.n
-            d.out, d.ldc = ptr(out), pk.n
-            d.add, d.ld_add = ptr(res), pk.n
-            d.dtype, d.zero_page = _CODE[pk.dtype], ptr(self._zero_page(x.device))
-            check(lib.bg_conv_gemm_fwd(ctypes.byref(d), stream()), "bg_conv_gemm_fwd")
-            return out, (S, Ho, Wo, pk.n)
-        a = torch.empty(rows, kh * kw * C, device=x.device, dtype=pk.dtype)
-        check(lib.bg_im2col(ptr(x), ptr(a), _CODE[pk.dtype], S, H, W, C, kh, kw, up, stride, py, px, Ho, Wo,
-                            ptr(st), ptr(g), ptr(b), norm.num_groups if norm is not None else 1, act, None, stream()),
-              "bg_im2col")
-        out = ops.linear(a, pk.w, pk.b, out_dtype=torch.float32, add=residual, add_div=1, n_valid=pk.n)
-        return out, (S, Ho, Wo, pk.n)
-
-    def _resnet(self, x, shape, P, name, r):
-        S, H, W, C = shape
-        h, hs = self._conv(x, shape, P[name + "c1"], 3, 3, norm=r.norm1, act=ACT_SILU)
-        if name + "sc" in P:
-            x, _ = self._conv(x, shape, P[name + "sc"], 1, 1)
-        out, os_ = self._conv(h, hs, P[name + "c2"], 3, 3, norm=r.norm2, act=ACT_SILU, residual=x)
-        return out, os_
-
-    def _attn2d(self, x, shape, P, key, at):
-        """diffusers Attention of the 2-D mid block: 1 head over H*W tokens, dim_head = C."""
-        S_, H, W, C = shape
-        qkv, _ = self._conv(x, shape, P[key + "qkv"], 1, 1, norm=at.group_norm)
-        o = torch.empty(S_ * H * W, C, device=x.device, dtype=P[key + "proj"].dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S_, H * W, C, 1, 1.0 / math.sqrt(C),
-                                        stream()), "bg_small_attn")
-        return ops.linear(o, P[key + "proj"].w, P[key + "proj"].b, out_dtype=torch.float32, add=x, n_valid=C)
-
     def _pack_resnet2d(self, P, name, r, dt):
         P[name + "c1"], P[name + "c2"] = self._pack_conv(r.conv1, dt), self._pack_conv(r.conv2, dt)
         if hasattr(r, "conv_shortcut"):
@@ -409,39 +344,6 @@ class _HipVAE(nn.Module):
         P[key + "qkv"] = self._pack_gemm(torch.cat([at.query.weight, at.key.weight, at.value.weight]),
                                          torch.cat([at.query.bias, at.key.bias, at.value.bias]), dt)
         P[key + "proj"] = self._pack_gemm(at.proj_attn.weight, at.proj_attn.bias, dt)
-
-    def _resconv(self, x, shape, P, name, r):
-        # ResConvBlock: conv k5 -> GroupNorm(1) -> GELU -> conv k5 -> GroupNorm(1) -> GELU, + (1x1) skip.
-        # group_norm_1 + GELU fold into the gather of conv_2; the trailing group_norm_2 + GELU cannot fold into the
-        # next consumer (the residual add sits in between), so it is one 1x1 "im2col" pass with the add fused.
-        h, hs = self._conv(x, shape, P[name + "c1"], 1, 5)
-        h, hs = self._conv(h, hs, P[name + "c2"], 1, 5, norm=r.group_norm_1, act=ACT_GELU)
-        S, H, W, C = hs
-        res = x
-        if name + "sk" in P:
-            res, _ = self._conv(x, shape, P[name + "sk"], 1, 1)
-        st = self._stats(h, S, H * W, C, r.group_norm_2)
-        y = torch.empty(S * H * W, C, device=h.device, dtype=torch.float32)
-        check(_lib.load().bg_im2col(ptr(h), ptr(y), BG_F32, S, H, W, C, 1, 1, 0, 1, 0, 0, H, W, ptr(st),
-                                    ptr(r.group_norm_2.weight.detach().float().contiguous()),
-                                    ptr(r.group_norm_2.bias.detach().float().contiguous()), 1, ACT_GELU,
-                                    ptr(res.contiguous()), stream()),
-              "bg_im2col[norm+gelu+residual]")
-        return y, hs
-
-    def _attn1d(self, x, shape, P, key, at):
-        S, H, W, C = shape
-        qkv, _ = self._conv(x, shape, P[key + "qkv"], 1, 1, norm=at.group_norm)
-        nh = C // 32
-        pk = P[key + "proj"]
-        o = torch.empty(S * W, C, device=x.device, dtype=pk.dtype)
-        check(_lib.load().bg_small_attn(ptr(qkv), 3 * C, ptr(o), _CODE[o.dtype], S,
-                                        H * W, C, nh, 1.0 / math.sqrt(C // nh), stream()), "bg_small_attn")
-        return ops.linear(o, pk.w, pk.b, out_dtype=torch.float32, add=x, n_valid=C)
-
-    def _chunk(self, n, per_sample_bytes):
-        return max(1, min(n, self.IM2COL_BUDGET // max(1, per_sample_bytes)))
-
 
 class AutoencoderKLFastDecode(_HipVAE):
     """Surface-VAE decoder: z [F,3,4,4] -> points [F,3,32,32]  (network.py:948-1040)."""
@@ -494,25 +396,6 @@ class AutoencoderKLFastDecode(_HipVAE):
         pg.conv(x, P["out"], 3, 3, norm=d.conv_norm_out, act=ACT_SILU, dst=VAE_OUT)
         return pg
 
-    def _decode_chunk(self, z_cl, dt):
-        """z_cl: channels-last fp32 [S,4,4,latent] -> [S,32,32,out]."""
-        P = self._pack(dt)
-        d = self.decoder
-        S = z_cl.shape[0]
-        shape = (S, z_cl.shape[1], z_cl.shape[2], self.latent)
-        x, shape = self._conv(z_cl, shape, P["pq"], 1, 1)
-        x, shape = self._conv(x, shape, P["in"], 3, 3)
-        x, shape = self._resnet(x, shape, P, "m0", d.mid_block.resnets[0])
-        x = self._attn2d(x, shape, P, "ma", d.mid_block.attentions[0])
-        x, shape = self._resnet(x, shape, P, "m1", d.mid_block.resnets[1])
-        for bi, blk in enumerate(d.up_blocks):
-            for ri, r in enumerate(blk.resnets):
-                x, shape = self._resnet(x, shape, P, f"u{bi}r{ri}", r)
-            if hasattr(blk, "upsamplers"):
-                x, shape = self._conv(x, shape, P[f"u{bi}up"], 3, 3, up=1)
-        x, shape = self._conv(x, shape, P["out"], 3, 3, norm=d.conv_norm_out, act=ACT_SILU)
-        return x.reshape(shape)
-
     def forward(self, z, return_dict=True, generator=None):
         if not z.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
@@ -524,12 +407,7 @@ class AutoencoderKLFastDecode(_HipVAE):
         dt = self._dtype()
         n = z_cl.shape[0]
         side = z_cl.shape[1] * 2 ** (len(self.block_out) - 1)
-        if self._use_executor():
-            return self._run(z_cl, (side, side, self.out_ch), dt)
-        worst = side * side * 9 * max(self.block_out[0] * 2, self.block_out[0]) * (4 if dt == torch.float32 else 2)
-        step = self._chunk(n, worst)
-        outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        return torch.cat(outs) if len(outs) > 1 else outs[0]
+        return self._run(z_cl, (side, side, self.out_ch), dt)
 
     def decode_tokens(self, surfZ):
         """Token-layout latents [..., 16*3] (position-major, channel-minor: what SurfZNet denoises) -> point grids
@@ -595,26 +473,6 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         pg.conv(x, P["out"], 1, 3, norm=d.conv_norm_out, act=ACT_SILU, dst=VAE_OUT)
         return pg
 
-    def _decode_chunk(self, z_cl, dt):
-        P = self._pack(dt)
-        d = self.decoder
-        S, L = z_cl.shape[0], z_cl.shape[1]
-        shape = (S, 1, L, self.latent)
-        x, shape = self._conv(z_cl, shape, P["pq"], 1, 1)
-        x, shape = self._conv(x, shape, P["in"], 1, 3)
-        for i in range(6):
-            x, shape = self._resconv(x, shape, P, f"m{i}", d.mid_block.resnets[i])
-            x = self._attn1d(x, shape, P, f"a{i}", d.mid_block.attentions[i])
-        for bi, blk in enumerate(d.up_blocks):
-            for ri, r in enumerate(blk.resnets):
-                x, shape = self._resconv(x, shape, P, f"u{bi}r{ri}", r)
-            S_, _, L_, C = shape
-            y = torch.empty(S_ * 2 * L_, C, device=x.device, dtype=torch.float32)
-            check(_lib.load().bg_upsample1d_cubic(ptr(x), ptr(y), S_, L_, C, stream()), "bg_upsample1d_cubic")
-            x, shape = y, (S_, 1, 2 * L_, C)
-        x, shape = self._conv(x, shape, P["out"], 1, 3, norm=d.conv_norm_out, act=ACT_SILU)
-        return x.reshape(shape[0], shape[2], shape[3])
-
     def forward(self, z, return_dict=True):
         if not z.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE decode runs on the MI355X only (tensor on {z.device})")
@@ -626,12 +484,7 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         dt = self._dtype()
         n = z_cl.shape[0]
         length = z_cl.shape[1] * 2 ** len(self.block_out)
-        if self._use_executor():
-            return self._run(z_cl, (length, self.out_ch), dt)
-        worst = length * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
-        step = self._chunk(n, worst)
-        outs = [self._decode_chunk(z_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        return torch.cat(outs) if len(outs) > 1 else outs[0]
+        return self._run(z_cl, (length, self.out_ch), dt)
 
     def decode_tokens(self, edgeZ):
         """Token-layout latents [..., 4*3] (the first 12 of EdgeZNet's 18 channels) -> polylines [..., 32, 3]; equals
@@ -751,23 +604,6 @@ class AutoencoderKLFastEncode(_HipVAE):
         pg.conv(x2, P["q"], 1, 1, dst=VAE_OUT, n_out=self.latent)       # DiagonalGaussianDistribution(moments).mode() = mean
         return pg
 
-    def _encode_chunk(self, x_cl, dt):
-        P, e = self._pack(dt), self.encoder
-        S = x_cl.shape[0]
-        shape = (S, x_cl.shape[1], x_cl.shape[2], self.in_ch)
-        x, shape = self._conv(x_cl, shape, P["in"], 3, 3)
-        for bi, blk in enumerate(e.down_blocks):
-            for ri, r in enumerate(blk.resnets):
-                x, shape = self._resnet(x, shape, P, f"d{bi}r{ri}", r)
-            if hasattr(blk, "downsamplers"):                      # Downsample2D: pad (0,1,0,1), conv 3x3 stride 2
-                x, shape = self._conv(x, shape, P[f"d{bi}dn"], 3, 3, stride=2, pad=(0, 0))
-        x, shape = self._resnet(x, shape, P, "m0", e.mid_block.resnets[0])
-        x = self._attn2d(x, shape, P, "ma", e.mid_block.attentions[0])
-        x, shape = self._resnet(x, shape, P, "m1", e.mid_block.resnets[1])
-        x, shape = self._conv(x, shape, P["out"], 3, 3, norm=e.conv_norm_out, act=ACT_SILU)
-        x, shape = self._conv(x, shape, P["q"], 1, 1)
-        return x.reshape(shape)[..., : self.latent]               # DiagonalGaussianDistribution(moments).mode() = mean
-
     def forward(self, x, return_dict=True):
         if not x.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {x.device})")
@@ -778,13 +614,8 @@ class AutoencoderKLFastEncode(_HipVAE):
         """Channels-last point grids [F,32,32,3] -> channels-last latent modes [F,4,4,3]."""
         dt = self._dtype()
         n, side = x_cl.shape[0], x_cl.shape[1]
-        if self._use_executor():
-            lat = side >> (len(self.block_out) - 1)
-            return self._run(x_cl, (lat, lat, self.latent), dt)
-        worst = side * side * 9 * self.block_out[0] * (4 if dt == torch.float32 else 2)
-        step = self._chunk(n, worst)
-        outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        return torch.cat(outs) if len(outs) > 1 else outs[0]
+        lat = side >> (len(self.block_out) - 1)
+        return self._run(x_cl, (lat, lat, self.latent), dt)
 
     def encode_tokens(self, surfPnt):
         """Point grids [..., 32, 32, 3] (the datasets' layout) -> token-layout latents [..., 48]; equals trainer.py:519-524
@@ -841,25 +672,6 @@ class AutoencoderKL1DFastEncode(_HipVAE):
         pg.conv(x2, P["q"], 1, 1, dst=VAE_OUT, n_out=self.latent)
         return pg
 
-    def _encode_chunk(self, x_cl, dt):
-        P, e = self._pack(dt), self.encoder
-        S, L = x_cl.shape[0], x_cl.shape[1]
-        shape = (S, 1, L, self.in_ch)
-        x, shape = self._conv(x_cl, shape, P["in"], 1, 3)
-        for bi, blk in enumerate(e.down_blocks):
-            S_, _, L_, C = shape
-            y = torch.empty(S_ * (L_ // 2), C, device=x.device, dtype=torch.float32)
-            check(_lib.load().bg_downsample1d_cubic(ptr(x), ptr(y), S_, L_, C, stream()), "bg_downsample1d_cubic")
-            x, shape = y, (S_, 1, L_ // 2, C)
-            for ri, r in enumerate(blk.resnets):
-                x, shape = self._resconv(x, shape, P, f"d{bi}r{ri}", r)
-        for i in range(6):
-            x, shape = self._resconv(x, shape, P, f"m{i}", e.mid_block.resnets[i])
-            x = self._attn1d(x, shape, P, f"a{i}", e.mid_block.attentions[i])
-        x, shape = self._conv(x, shape, P["out"], 1, 3, norm=e.conv_norm_out, act=ACT_SILU)
-        x, shape = self._conv(x, shape, P["q"], 1, 1)
-        return x.reshape(shape[0], shape[2], shape[3])[..., : self.latent]
-
     def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):
         if not sample.is_cuda:
             raise _lib.BrepgenHipError(f"brepgen_amd VAE encode runs on the MI355X only (tensor on {sample.device})")
@@ -870,12 +682,7 @@ class AutoencoderKL1DFastEncode(_HipVAE):
         """Channels-last polylines [G,32,3] -> channels-last latent modes [G,4,3]."""
         dt = self._dtype()
         n = x_cl.shape[0]
-        if self._use_executor():
-            return self._run(x_cl, (x_cl.shape[1] >> len(self.block_out), self.latent), dt)
-        worst = x_cl.shape[1] * 5 * self.block_out[-1] * (4 if dt == torch.float32 else 2)
-        step = self._chunk(n, worst)
-        outs = [self._encode_chunk(x_cl[i:i + step].contiguous(), dt) for i in range(0, n, step)]
-        return torch.cat(outs) if len(outs) > 1 else outs[0]
+        return self._run(x_cl, (x_cl.shape[1] >> len(self.block_out), self.latent), dt)
 
     def encode_tokens(self, edgePnt):
         """Polylines [..., 32, 3] -> token-layout latents [..., 12]; equals trainer.py:924-929

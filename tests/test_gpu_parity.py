@@ -298,7 +298,8 @@ def test_vae_decode_batch_independence(pc):
     z = torch.randn(40, 3, 4, generator=torch.Generator().manual_seed(3)).cuda()
     with torch.no_grad():
         full = m(z)
-        m.IM2COL_BUDGET = 1 << 18                       # force several chunks
+        m.WS_BUDGET = 1 << 22                           # force several chunks inside bg_vae_run
+        m.release_workspace()
         chunked = m(z)
         one = m(z[17:18])
     assert torch.equal(full, chunked) and float((full[17:18] - one).abs().max()) < 1e-5

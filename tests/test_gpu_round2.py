@@ -373,11 +373,10 @@ def test_vae_implicit_gemm_equals_materialised_im2col(pc, kind, n, dt):
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
     m.compute_dtype = dt
+    from vae_stepwise import stepwise
     with torch.no_grad():
-        m.implicit_gemm = True
-        a = m(z.cuda())
-        m.implicit_gemm = False
-        b = m(z.cuda())
+        a = stepwise(m, z.cuda(), implicit_gemm=True)
+        b = stepwise(m, z.cuda(), implicit_gemm=False)
         want = ref(sd, z[:4])
     assert torch.isfinite(a).all() and torch.equal(a, b)
     e = float((a[:4].cpu() - want).abs().max())
@@ -408,11 +407,10 @@ def test_vae_program_equals_step_by_step(pc, kind, n, dt):
     step-by-step driver: the results are the same bits (fp32 and bf16, decoders and encoders)."""
     m, z = _vae_case(pc, kind, n)
     m.compute_dtype = dt
+    from vae_stepwise import stepwise
     with torch.no_grad():
-        m.executor = True
         a = m(z)
-        m.executor = False
-        b = m(z)
+        b = stepwise(m, z)
     assert a.shape == b.shape and torch.isfinite(a).all() and torch.equal(a, b)
 
 

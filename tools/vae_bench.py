@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 import torch
 
 import brepgen_amd as bga
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from vae_stepwise import stepwise  # noqa: E402
 from brepgen_amd.pipeline import EDGE_VAE_CFG, SURF_VAE_CFG
 
 torch.manual_seed(0)
@@ -28,14 +30,15 @@ with torch.no_grad():
         for name, flag, ex in (("one_call_program", True, True), ("implicit_gemm", True, False), ("im2col", False, False)):
             if ONLY and name not in ONLY:
                 continue
-            surf.implicit_gemm = edge.implicit_gemm = flag
-            surf.executor = edge.executor = ex
+            # (product path = one bg_vae_run program per pass; the two step-by-step baselines live in tests/vae_stepwise.py)
+            dec_s = (lambda z: surf.decode_tokens(z)) if ex else (lambda z: stepwise(surf, z.reshape(-1, 4, 4, 3).permute(0, 3, 1, 2), implicit_gemm=flag))
+            dec_e = (lambda z: edge.decode_tokens(z)) if ex else (lambda z: stepwise(edge, z.reshape(-1, 4, 3).permute(0, 2, 1), implicit_gemm=flag))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            a = surf.decode_tokens(zs)
+            a = dec_s(zs)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            b = edge.decode_tokens(ze)
+            b = dec_e(ze)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             out.setdefault(name, []).append({"surf_s": round(t1 - t0, 3), "edge_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3),
