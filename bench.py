@@ -505,6 +505,7 @@ def main():
                     "launches_per_step": round(dom["launches"] / args.steps, 2),
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "flops": "executed (valid rows only) over the launches of the three loops",
                     "measured_with": "launches serialised (n_split = 1); the timed region runs n_split = %d" % n_split}
         # every GEMM kernel of the step together (the 256 x 256 kernel takes the row panels that fill whole rounds, the

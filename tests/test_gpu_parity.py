@@ -282,8 +282,11 @@ def test_vae_decode_fp32(pc, kind, n):
 
 @pytest.mark.parametrize("kind,n", [("surf", 3), ("edge", 7)])
 def test_vae_decode_bf16(pc, kind, n):
+    # measured on MI355X (tools/vae_small_parity.py, profiles/r03/vae_small_parity.log): max 0.7-0.9 % of |ref|max, mean
+    # 2.7-4.1e-3; asserted at 2x.  The same passes at sizes that take the implicit-GEMM path, next to torch.autocast of the
+    # oracle: tests/test_gpu_round3.py::test_vae_decode_large_vs_oracle_and_torch_autocast
     e = pc.vae_case(kind, n, BF16)
-    assert e["finite"] and e["max_abs"] < 0.15 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.03
+    assert e["finite"] and e["max_abs"] < 0.02 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.009
 
 
 def test_vae_decode_batch_independence(pc):
@@ -349,8 +352,8 @@ def test_autocast_selects_operand_dtype(pc):
 
 @pytest.mark.parametrize("kind,n", [("surf", 2), ("edge", 5)])
 def test_vae_decode_fp16(pc, kind, n):
-    e = pc.vae_case(kind, n, F16)
-    assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])
+    e = pc.vae_case(kind, n, F16)                                  # measured 0.09-0.14 % of |ref|max, mean 3.7-5.3e-4
+    assert e["finite"] and e["max_abs"] < 0.003 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.0012
 
 
 # ---- VAE encoders (training-time API surface) ------------------------------------------
@@ -367,10 +370,10 @@ def test_vae_encode_fp32(pc, kind, n):
 
 @pytest.mark.parametrize("kind,n", [("surf_enc", 2), ("edge_enc", 6)])
 def test_vae_encode_16bit(pc, kind, n):
-    e = pc.vae_case(kind, n, BF16)
-    assert e["finite"] and e["max_abs"] < 0.15 * max(1.0, e["ref_absmax"])
-    e = pc.vae_case(kind, n, F16)
-    assert e["finite"] and e["max_abs"] < 0.03 * max(1.0, e["ref_absmax"])
+    e = pc.vae_case(kind, n, BF16)                                 # measured 0.66 / 1.03 % of |ref|max, mean 3.2-3.5e-3
+    assert e["finite"] and e["max_abs"] < 0.022 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.008
+    e = pc.vae_case(kind, n, F16)                                  # measured 0.10 / 0.15 %, mean 4.9-5.7e-4
+    assert e["finite"] and e["max_abs"] < 0.003 * max(1.0, e["ref_absmax"]) and e["mean_abs"] < 0.0012
 
 
 def test_per_sample_timesteps_training_style(pc):

@@ -22,7 +22,7 @@ if [[ $WHAT == all || $WHAT == prof ]]; then
   # the bench command as the driver runs it (product default: two sample groups in flight), and with serialised launches
   for sp in 0 1; do
     rm -rf $O/prof_stats_split$sp
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_split$sp -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-extra --split $sp > $O/prof_stats_split$sp.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_split$sp -o bench -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --no-extra --split $sp > $O/prof_stats_split$sp.log 2>&1
     echo "rocprof stats (split $sp) rc=$?" >> $O/prof_stats_split$sp.log
   done
   cd $R
@@ -34,7 +34,7 @@ if [[ $WHAT == all || $WHAT == pmc ]]; then
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
     rm -rf $O/pmc$i
-    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extra --split 1 > $O/pmc$i.log 2>&1
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o pmc -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-extra --split 1 > $O/pmc$i.log 2>&1
     echo "pmc$i rc=$? ($set)" >> $O/pmc$i.log
   done
   cd $R
