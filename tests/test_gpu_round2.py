@@ -142,44 +142,50 @@ def _build_sampler(dist, use_cf, noise_mode):
 SCHED = dict(pndm_pos_steps=13, ddpm_pos_steps=4, pndm_z_steps=13)
 
 
-def _rank_main(rank, world, port, B, S, E, noise_mode, q):
+def _rank_main(rank, world, port, Bs, S, E, noise_mode, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)                              # both ranks share the one GPU of the test box
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sampler = _build_sampler(dist, False, noise_mode)
-        out = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(31), **SCHED)
-        q.put((rank, {k: v.cpu().numpy().copy() for k, v in out.items()}))     # by value: no handle to fetch from an exited process
+        for B in Bs:                                      # several batch sizes per spawn: the process start-up dominates the test
+            out = sampler.sample(B, S, E, generator=torch.Generator().manual_seed(31 + B), **SCHED)
+            q.put((rank, B, {k: v.cpu().numpy().copy() for k, v in out.items()}))     # by value: no handle to fetch from an exited process
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,noise_mode", [(2, "device"), pytest.param(2, "reference", marks=pytest.mark.slow), (4, "device")])
+@pytest.mark.parametrize("world,noise_mode", [(2, "device"), pytest.param(2, "reference", marks=pytest.mark.slow),
+                                              pytest.param(4, "device", marks=pytest.mark.slow)])
 def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
-    """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with an UNEVEN split --
-    B = 3 samples: world 2 -> shards of 2 and 1, world 4 -> one rank owns nothing -- equals the single-process cascade
-    bit for bit: per-sample kernels, noise keyed on the global sample index, one padded all-gather."""
+    """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with UNEVEN splits --
+    B = 3 samples: world 2 -> shards of 2 and 1, world 4 -> one rank owns nothing; B = 1: only rank 0 owns a sample, the others
+    skip the compute and still join the collective -- equals the single-process cascade bit for bit: per-sample kernels, noise
+    keyed on the global sample index, one padded all-gather.  (Both batch sizes run in the same processes.)"""
     import torch.multiprocessing as mp
-    B, S, E = 3, 4, 3
-    want = _build_sampler(None, False, noise_mode).sample(B, S, E, generator=torch.Generator().manual_seed(31), **SCHED)
-    want = {k: v.cpu() for k, v in want.items()}
+    Bs, S, E = (3, 1), 4, 3
+    ref = _build_sampler(None, False, noise_mode)
+    want = {B: {k: v.cpu() for k, v in ref.sample(B, S, E, generator=torch.Generator().manual_seed(31 + B), **SCHED).items()} for B in Bs}
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, B, S, E, noise_mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, Bs, S, E, noise_mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in (q.get(timeout=600) for _ in range(world))}
+    got = {}
+    for _ in range(world * len(Bs)):
+        r, B, d = q.get(timeout=600)
+        got[(r, B)] = {k: torch.from_numpy(v) for k, v in d.items()}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    for r in range(world):
-        assert set(got[r]) == set(want)
-        for k in want:
-            assert got[r][k].shape == want[k].shape and got[r][k].dtype == want[k].dtype, (r, k)
-            assert torch.equal(got[r][k], want[k]), f"rank {r} tensor {k}"
+    for (r, B), g in got.items():
+        assert set(g) == set(want[B])
+        for k in want[B]:
+            assert g[k].shape == want[B][k].shape and g[k].dtype == want[B][k].dtype, (r, B, k)
+            assert torch.equal(g[k], want[B][k]), f"rank {r} batch {B} tensor {k}"
 
 
 # ---- variable-length execution (valid tokens only) ---------------------------------------------------------------------
