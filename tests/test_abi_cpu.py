@@ -163,3 +163,26 @@ def test_product_does_not_import_oracle():
     bench = open(os.path.join(ROOT, "bench.py")).read()
     for m in re.finditer(r"^(\s*)(from|import)\s+oracle", bench, flags=re.M):
         assert len(m.group(1)) > 0 and "def cpu_baseline" in bench[:m.start()], "oracle import outside cpu_baseline()"
+
+
+def test_p256_kernels_do_not_spill():
+    """csrc/gemm_p256.hip keeps LDS-DMA in flight across its whole K loop with hand-counted vmcnt waits; a register spill would
+    put scratch loads (vector-memory operations hipcc follows with vmcnt(0)) into that stream -- the pipeline would drain at
+    every reload, and a spilled destination of the split epilogue's inline-asm residual loads would be read before it lands.
+    The build must therefore stay spill-free: 0 bytes of scratch for the plain / LayerNorm-fold kernels, at most one
+    loop-invariant dword for the split-residual ones."""
+    import re
+    import subprocess
+    from brepgen_amd import build as b
+    src = os.path.join(b.CSRC, "gemm_p256.hip")
+    r = subprocess.run([b._hipcc(), *b.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) and len(names) >= 11
+    for n, sc in zip(names, scratch):
+        if "gemm16_p256_kernel" not in n:
+            continue
+        split = "ELi3E" in n                                     # MODE = P_SPLIT in the mangled name
+        assert sc <= (8 if split else 0), (n, sc)
