@@ -59,7 +59,7 @@ template <bool F16, int MODE, bool NARROW, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_epilogue, int stagger_units, int nt_stores) {
     constexpr bool FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16 || MODE == P_SPLIT, "16-bit output epilogues only");
-    static_assert(NARROW == FOLD || MODE == P_PLAIN16, "the LayerNorm-fold epilogue is written for 32-column passes");
+    static_assert(!(SPLIT && NARROW), "the split-residual epilogue has its own slab shape");
     static_assert(SPLIT || !STATS, "row statistics are an output of the split-residual epilogue");
     using E = Elem<F16>;
     using T = typename E::T;
@@ -149,8 +149,9 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                 if (has_bias) dma(patch_lds + 2048u, reinterpret_cast<const unsigned char*>(g.bias + n0c + wn * 64), (unsigned)ln * 16u);
                 if (FOLD) dma(patch_lds + 2304u, reinterpret_cast<const unsigned char*>(g.colsum + n0c + wn * 64), (unsigned)ln * 16u);
             }
-        } else if (has_bias) {
-            dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), (unsigned)ln * 16u);
+        } else {                                                  // the tile's 256 columns: [0, 1K) bias, [1K, 2K) column sums
+            if (has_bias) dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), (unsigned)ln * 16u);
+            if (FOLD) dma(patch_lds + 1024u, reinterpret_cast<const unsigned char*>(g.colsum + n0c), (unsigned)ln * 16u);
         }
     };
     // LayerNorm fold: the (rstd, -mean * rstd) pairs of the wave's 128 rows come from g.ln_coef (one pair per row, written by
@@ -426,13 +427,21 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                 res_wait(6, 8);
                 slab(6); slab(7);
             } else if constexpr (!NARROW) {
-                // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias
-                float4 bz[2][4];
+                // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias (LayerNorm fold: and of
+                // column sums, plus the (rstd, -mean rstd) pairs of its four rows) -- read before the first pass overwrites the patch
+                float4 bz[2][4], cs[2][4];
+                float2 cf[4];
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        bz[j][q] = has_bias ? *reinterpret_cast<const float4*>(patch + (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u) : zero4;
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned off = (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u;
+                        bz[j][q] = has_bias ? *reinterpret_cast<const float4*>(patch + off) : zero4;
+                        cs[j][q] = FOLD ? *reinterpret_cast<const float4*>(patch + 1024 + off) : zero4;
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cf[i] = FOLD ? reinterpret_cast<const float2*>(patch + 2560)[i * 32 + l31] : make_float2(1.f, 0.f);
                 // patch rows of 128 B; 16-byte chunk (j*4 + q) XOR-swizzled by the row; rows 8-15 / 24-31 swap the two 8-byte
                 // halves, so the 16 lanes of a ds_write_b64 service group hit 32 distinct banks
                 const unsigned wr_base = (unsigned)l31 * 128u + (unsigned)((hq ^ ((l31 >> 3) & 1)) * 8);
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             *reinterpret_cast<uint2*>(patch + wr_base + (unsigned)(((j * 4 + q) ^ (l31 & 7)) * 16)) =
-                                quad(i, j, q, bz[j][q], zero4, make_float2(1.f, 0.f));
+                                quad(i, j, q, bz[j][q], cs[j][q], cf[i]);
                     __builtin_amdgcn_wave_barrier();              // LDS executes a wave's accesses in order: no wait needed
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
@@ -545,7 +554,8 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
     const int nt = g_tune[TUNE_P256_NT];                          // bit 0: non-temporal output stores, bit 1: vmcnt(0) waits in the split epilogue
     if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else if (g.stats_in && g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else if (g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
     return launch_status("gemm16_p256");

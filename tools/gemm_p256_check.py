@@ -87,7 +87,7 @@ for dt in (torch.bfloat16, torch.float16):
 print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
 TIMING = True
 # (name, mode (key 10: 0 = hybrid 256 + 128, 1 = 256 alone, 2 = 128 alone), align (key 9: 2 = staggered wave groups), start stagger (12), nt (13), narrow (14))
-VARS = [("128", 2, 0, 0, 0, 0), ("256", 1, 0, 0, 0, 0), ("hybrid", 0, 0, 0, 0, 0)]
+VARS = [("128", 2, 0, 0, 0, 0), ("256", 1, 0, 0, 0, 0), ("256 narrow", 1, 0, 0, 0, 1), ("hybrid", 0, 0, 0, 0, 0)]
 for M in MS:
     cases = build(M, dt)
     res = {(k, v[0]): [] for k in cases for v in VARS}
