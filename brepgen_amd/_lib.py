@@ -121,6 +121,7 @@ _SIGNATURES = {
     "bg_profile_begin": (C.c_int, [C.c_int]),
     "bg_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int]),
     "bg_tune_set": (C.c_int, [C.c_int, C.c_int]),
+    "bg_gemm_p256_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
     "bg_chamfer_offset_fit": (C.c_int, [fp, fp, vp, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5 + [fp, fp, fp, vp]),
     "bg_philox_randn": (C.c_int, [fp, C.c_longlong, C.c_int, C.c_ulonglong, C.c_uint, C.c_longlong, C.c_int, vp]),

@@ -34,7 +34,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 };
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
-enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_ALIGN = 9, TUNE_P256_MODE = 10, TUNE_P256_MIN_TILES = 11, TUNE_P256_STAGGER = 12, TUNE_P256_NT = 13, TUNE_P256_NARROW = 14, TUNE_COUNT = 16 };
+enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------

@@ -373,6 +373,11 @@ extern "C" int bg_tune_set(int key, int value) {
     return 0;
 }
 
+extern "C" int bg_gemm_p256_rows(int rows, int n_cols, int split_residual, int concurrent) {
+    BG_REQUIRE(rows >= 0 && n_cols > 0 && (n_cols & 255) == 0, BG_E_ARG, "bg_gemm_p256_rows: rows >= 0 and n_cols a positive multiple of 256 expected");
+    return bg::p256_rows(rows, n_cols >> 8, split_residual != 0, concurrent != 0);
+}
+
 extern "C" int bg_abi_version(void) { return BG_ABI_VERSION; }
 extern "C" const char* bg_last_error(void) { return bg::g_err; }
 

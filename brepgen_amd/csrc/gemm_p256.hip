@@ -55,11 +55,10 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-template <bool F16, int MODE, bool NARROW, bool STATS = false>
-__global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_epilogue, int stagger_units, int nt_stores) {
+template <bool F16, int MODE, bool STATS = false>
+__global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     constexpr bool FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16 || MODE == P_SPLIT, "16-bit output epilogues only");
-    static_assert(!(SPLIT && NARROW), "the split-residual epilogue has its own slab shape");
     static_assert(SPLIT || !STATS, "row statistics are an output of the split-residual epilogue");
     using E = Elem<F16>;
     using T = typename E::T;
@@ -80,16 +79,6 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     // an A panel is fetched into that L2 once and the W tiles stay resident.
     int L = xcd_remap(blockIdx.x, G);
     if (L >= T_all) return;                                       // uniform per workgroup, before any barrier
-    // Start stagger.  Launched together with equal tiles, all 256 workgroups would reach their epilogues at the same moment, every
-    // round: 32 MB of output hit the fabric at once (measured: ~6.5 us per round at ~5 TB/s) while the memory system idles during
-    // the K loops.  Workgroup b therefore starts c(b) x stagger_units x 64 cycles late, c in 0..31, once per launch: the epilogues
-    // of a round then arrive spread over about one burst length and each drains at its own CU's rate (the host sets
-    // stagger_units = 0 for launches of a single round, where the delay would cost more than it saves).
-    if (stagger_units > 0) {
-        const int c = ((int)(blockIdx.x >> 3) + 4 * (int)(blockIdx.x & 7)) & 31;
-        for (int n = c * stagger_units; n > 0; --n) __builtin_amdgcn_s_sleep(1);
-    }
-
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.a);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.w);
     const unsigned lda_b = (unsigned)g.lda * 2u, ldw_b = (unsigned)g.K * 2u;
@@ -133,26 +122,15 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
     }
     const unsigned w_half = 128u * ldw_b;                         // W rows 128-255: the same lane offsets on a shifted base
 
-    // Epilogue operands wait in the wave's patch while the K loop runs (no registers).  Two epilogue shapes:
-    //   * !NARROW (plain output): passes of 32 rows x 64 columns fill the 4 KiB patch; the tile's bias (1 KiB = 256 columns, one
-    //     LDS-DMA piece) sits in [0, 1K) between epilogues and is read into registers before the first pass overwrites it;
-    //   * NARROW (LayerNorm fold, or plain as an A/B): passes of 32 rows x 32 columns use [0, 2K); [2K, 2K+256) holds the wave's 64
-    //     bias values, [2K+256, 2K+512) its 64 column sums, [2.5K, 3.5K) the (rstd, -mean rstd) pairs of the wave's 128 rows -- read
-    //     per pass, so the epilogue never holds more than one column tile's constants in registers.
-    // The column vectors are DMA'd at the END of the previous tile's epilogue (here: in the prologue): an L2 round trip per tile
-    // would otherwise sit in front of every epilogue, and a plain load there would make hipcc wait for vmcnt(0), i.e. for the
-    // next tile's DMA as well.
+    // Epilogue operands wait in the wave's patch while the K loop runs (no registers): [0, 1K) the tile's 256 bias values, [1K, 2K)
+    // its 256 column sums (LayerNorm fold), [2.5K, 3.5K) the (rstd, -mean rstd) pairs of the wave's 128 rows -- one 1 KiB LDS-DMA
+    // piece each, issued at the END of the previous tile's epilogue (here: in the prologue) and read into registers before the first
+    // pass of this tile's epilogue overwrites the patch.  An L2 round trip per tile would otherwise sit in front of every epilogue,
+    // and a plain load there would make hipcc wait for vmcnt(0), i.e. for the next tile's DMA as well.
     auto stage_cols = [&](int n0c) {
-        const int ln = opaque(threadIdx.x & 63);
-        if (NARROW) {
-            if (ln < 16) {                                        // 16 lanes x 16 B = this wave's 64 columns
-                if (has_bias) dma(patch_lds + 2048u, reinterpret_cast<const unsigned char*>(g.bias + n0c + wn * 64), (unsigned)ln * 16u);
-                if (FOLD) dma(patch_lds + 2304u, reinterpret_cast<const unsigned char*>(g.colsum + n0c + wn * 64), (unsigned)ln * 16u);
-            }
-        } else {                                                  // the tile's 256 columns: [0, 1K) bias, [1K, 2K) column sums
-            if (has_bias) dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), (unsigned)ln * 16u);
-            if (FOLD) dma(patch_lds + 1024u, reinterpret_cast<const unsigned char*>(g.colsum + n0c), (unsigned)ln * 16u);
-        }
+        const unsigned voff = (unsigned)opaque(threadIdx.x & 63) * 16u;
+        if (has_bias) dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), voff);
+        if (FOLD) dma(patch_lds + 1024u, reinterpret_cast<const unsigned char*>(g.colsum + n0c), voff);
     };
     // LayerNorm fold: the (rstd, -mean * rstd) pairs of the wave's 128 rows come from g.ln_coef (one pair per row, written by
     // ln_coef_kernel ahead of this launch) as one 1 KiB LDS-DMA piece, like the column vectors.  (The row statistics themselves
@@ -286,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
         iteration(w_cur + (unsigned)(KT - 1) * (2 * G_BK), has_next, a_nxt, w_nxt, a_nxt + 2 * G_BK);
 
         // ---------------- epilogue ----------------
-        if (align_epilogue && wm == 0) bar();                     // both wave groups run their epilogues together (see launcher)
+        if (wm == 0) bar();           // both wave groups run their epilogues together (one barrier apart they serialise: measured slower)
         {
             const int ln = opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
             const int rbase = m0 + wm * 128, cbase = n0 + wn * 64;
@@ -296,8 +274,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                 if (grow < Mv) {
                     u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)grow * g.ldc + col);
                     const u32x4 vv = {v.x, v.y, v.z, v.w};
-                    if (nt_stores & 1) __builtin_nontemporal_store(vv, dst);
-                    else *dst = vv;
+                    *dst = vv;
                 }
             };
             // one accumulator quad (row l31 of row tile i, columns j*32 + 8 q + 4 hq .. +3) -> 4 x 16 bit
@@ -426,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                 res_issue(6); res_issue(7);
                 res_wait(6, 8);
                 slab(6); slab(7);
-            } else if constexpr (!NARROW) {
+            } else {
                 // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias (LayerNorm fold: and of
                 // column sums, plus the (rstd, -mean rstd) pairs of its four rows) -- read before the first pass overwrites the patch
                 float4 bz[2][4], cs[2][4];
@@ -463,35 +440,6 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-            } else {
-                // patch rows of 64 B (32 columns); 16-byte chunk q XOR-swizzled by (row >> 1) & 3: ds_read_b128 conflict-free,
-                // ds_write_b64 2-way (costs nothing at its issue rate)
-                const unsigned wr_base = (unsigned)l31 * 64u + (unsigned)(hq * 8);
-                const unsigned rd_row = (unsigned)(ln >> 2);
-                auto pass = [&](int i, int j) {
-                    float4 b[4], c[4];
-                    float2 cf = make_float2(1.f, 0.f);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned off = (unsigned)(j * 32 + 8 * q + 4 * hq) * 4u;
-                        b[q] = has_bias ? *reinterpret_cast<const float4*>(patch + 2048 + off) : zero4;
-                        c[q] = FOLD ? *reinterpret_cast<const float4*>(patch + 2304 + off) : zero4;
-                    }
-                    if (FOLD) cf = reinterpret_cast<const float2*>(patch + 2560)[i * 32 + l31];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<uint2*>(patch + wr_base + (unsigned)((q ^ ((l31 >> 1) & 3)) * 16)) = quad(i, j, q, b[q], c[q], cf);
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const unsigned row = it * 16 + rd_row;
-                        const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 64u + (((ln & 3) ^ ((row >> 1) & 3)) * 16));
-                        store16(rbase + i * 32 + (int)row, cbase + j * 32 + (ln & 3) * 8, v);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                };
-                pass(0, 0); pass(0, 1); pass(1, 0); pass(1, 1);
-                pass(2, 0); pass(2, 1); pass(3, 0); pass(3, 1);
             }
             if (has_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the patch accesses above are complete
@@ -500,10 +448,9 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g, int align_
             }
         }
         if (!has_next) break;
-        if (align_epilogue && wm == 1) bar();                     // restore the one-barrier lag of waves 4-7
+        if (wm == 1) bar();                                       // restore the one-barrier lag of waves 4-7
         L = Ln; m0 = m0n; n0 = n0n; a_cur = a_nxt; w_cur = w_nxt;
     }
-    if (!align_epilogue && wm == 0) bar();                        // pairs with the extra barrier of waves 4-7
 }
 
 // (sum, sum of squares) partials per 64-column group [K/64][M][2] -> (rstd, -mean * rstd) per row [M][2], in the association order
@@ -547,17 +494,10 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
         const int rc = launch_status("ln_coef");
         if (rc) return rc;
     }
-    const int align = g_tune[TUNE_P256_ALIGN] != 2;               // bg_tune key 9: 2 = wave groups enter the epilogue one barrier apart
-    // start stagger (see the kernel; bg_tune key 12 = units + 1): measured a loss at every setting (profiles/r03/
-    // gemm_p256_knob_sweep.log: lock-step workgroups share their A / W fetches in the L2), so it is off unless asked for
-    const int stg = g_tune[TUNE_P256_STAGGER] > 1 && tiles >= 2 * 256 - 64 ? g_tune[TUNE_P256_STAGGER] - 1 : 0;
-    const int nt = g_tune[TUNE_P256_NT];                          // bit 0: non-temporal output stores, bit 1: vmcnt(0) waits in the split epilogue
-    if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else if (g.stats_in && g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else if (g_tune[TUNE_P256_NARROW]) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
-    else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(512), 0, s, g, align, stg, nt);
+    if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(512), 0, s, g);
+    else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(512), 0, s, g);
+    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16>), dim3(grid), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16>), dim3(grid), dim3(512), 0, s, g);
     return launch_status("gemm16_p256");
 }
 template int launch_p256<false>(const GemmArgs&, hipStream_t);

@@ -378,8 +378,16 @@ typedef struct {
 int bg_profile_begin(int max_launches);
 int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number of rows written (<0: error) */
 
-/* Kernel-selection knob for A/B measurements (key 0: bf16 GEMM tile/pipeline variant, 0 = shipped default). */
+/* Kernel-selection knob for A/B measurements (key 0: 16-bit GEMM tile/pipeline variant, 0 = shipped default;
+ * key 10: the 256 x 256 persistent kernel -- 0 = the library's 256 + 128 partition, 1 = alone, 2 = never). */
 int bg_tune_set(int key, int value);
+
+/* How a 16-bit GEMM launch of `rows` x `n_cols` (n_cols a multiple of 256) is partitioned between the 256 x 256
+ * persistent kernel (rows [0, return value)) and the 128 x 128 one (the rest): the rule both kernels evaluate on the
+ * device-side row count and the launcher evaluates on the host ("tile-round quantisation").
+ * split_residual: the out-proj / FFN2 epilogue; concurrent: launches of sibling sample groups are in flight
+ * (all-or-nothing).  No device work; usable without a GPU.  <0: error code. */
+int bg_gemm_p256_rows(int rows, int n_cols, int split_residual, int concurrent);
 
 /* DDPMScheduler.add_noise (training-time forward diffusion, trainer.py:348,399,515,...):
  *   out[b,:] = sqrt_alpha_prod[b] * x0[b,:] + sqrt_one_minus_alpha_prod[b] * noise[b,:]

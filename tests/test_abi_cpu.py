@@ -180,9 +180,37 @@ def test_p256_kernels_do_not_spill():
     assert r.returncode == 0, r.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", r.stderr)
     scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
-    assert len(names) == len(scratch) and len(names) >= 11
+    assert len(names) == len(scratch) and len(names) >= 9              # ln_coef + {bf16, fp16} x {plain, fold, split, split + stats}
     for n, sc in zip(names, scratch):
         if "gemm16_p256_kernel" not in n:
             continue
         split = "ELi3E" in n                                     # MODE = P_SPLIT in the mangled name
         assert sc <= (8 if split else 0), (n, sc)
+
+
+def test_gemm_partition_rule_between_the_256_and_128_kernels():
+    """bg_gemm_p256_rows is the rule both GEMM kernels evaluate on the device-side row count (csrc/bg_common.h p256_rows):
+    the 256 x 256 kernel takes whole 256-row panels from the front, never more than the launch has, whole tile rounds
+    unless the last round is well filled; the known answers are the face-LDM shapes of DESIGN.md section 4."""
+    lib = _lib.load()
+    f = lib.bg_gemm_p256_rows
+    assert f(-1, 2304, 0, 0) == -1 and f(100, 100, 0, 0) == -1
+    for n_cols in (768, 1024, 2304):
+        nt = n_cols // 256
+        for split in (0, 1):
+            for conc in (0, 1):
+                for rows in list(range(0, 1200, 37)) + [8640, 15360, 17280, 17293, 30720, 30797, 61440, 138752, 1 << 20]:
+                    p = f(rows, n_cols, split, conc)
+                    panels = (rows + 255) // 256
+                    assert p % 256 == 0 and 0 <= p <= panels * 256, (rows, n_cols, split, conc, p)
+                    if conc:
+                        assert p in (0, panels * 256)                      # all or nothing next to sibling launches
+                    elif 0 < p < panels * 256:
+                        assert (p // 256 * nt) <= (panels * nt) // 256 * 256   # a partial take never starts a round it cannot fill
+    # QKV of the compacted 512 x 60 face batch (17 280 rows, 9 column tiles): 68 panels = 612 tiles -> two full rounds (56 panels)
+    # on the 256 kernel, 12 panels on the 128 kernel; the dense batch (30 720 rows = 1080 tiles, last round 56 tiles): 4 rounds
+    assert f(17280, 2304, 0, 0) == 56 * 256 and f(30720, 2304, 0, 0) == (1024 // 9) * 256
+    assert f(17280, 2304, 0, 1) == 68 * 256                                   # concurrent sample groups: >= 400 tiles -> alone
+    # out-proj / FFN2 (3 column tiles): 204 tiles fill one round well enough; 360 tiles do not pay (128 kernel alone)
+    assert f(17280, 768, 1, 0) == 68 * 256 and f(30720, 768, 1, 0) == 0 and f(138752, 768, 1, 0) > 0
+    assert f(100, 768, 0, 0) == 0 and f(0, 2304, 0, 0) == 0                 # a few tiles: the 128 kernel (finer tiles fill more CUs)

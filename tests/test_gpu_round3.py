@@ -38,12 +38,11 @@ def _record(key, value):
 
 @pytest.fixture
 def tune():
-    """bg_tune_set with automatic reset of the 256-kernel knobs (keys 9-14)."""
+    """bg_tune_set with automatic reset of the 256-kernel mode (key 10)."""
     from brepgen_amd import _lib
     lib = _lib.load()
     yield lib.bg_tune_set
-    for k in range(9, 15):
-        lib.bg_tune_set(k, 0)
+    lib.bg_tune_set(10, 0)
 
 
 # ---- the 256 x 256 persistent GEMM -------------------------------------------------------------------------------------
@@ -68,19 +67,18 @@ def _gemm_cases(M, dt, seed=0):
 @pytest.mark.parametrize("dt", [BF16, F16])
 @pytest.mark.parametrize("M", [1037, 256 * 7, 129, 17293])
 def test_p256_gemm_is_bit_identical_to_the_128_kernel(pc, tune, dt, M):
-    """Plain and LayerNorm-fold epilogues, ragged row counts, the 256 kernel alone (key 10 = 1; wave groups aligned /
-    one barrier apart, wide / narrow epilogue passes) and as the 256 + 128 hybrid (key 10 = 0; at M = 17 293 the QKV launch
-    splits into two full rounds on the 256 kernel + 11 row panels on the 128 kernel).  Repeated: a race in the 8-phase
-    K loop would not necessarily show the first time."""
+    """Plain and LayerNorm-fold epilogues, ragged row counts, the 256 kernel alone (key 10 = 1) and as the 256 + 128 hybrid
+    (key 10 = 0; at M = 17 293 the QKV launch splits into two full rounds on the 256 kernel + 11 row panels on the 128
+    kernel).  Repeated: a race in the 8-phase K loop would not necessarily show the first time."""
     for name, fn in _gemm_cases(M, dt).items():
         tune(10, 2)
         ref = fn().clone()
-        for mode, align, narrow in ((1, 0, 0), (1, 2, 1), (0, 0, 0)):
-            tune(10, mode); tune(9, align); tune(14, narrow)
-            for _ in range(2):
+        for mode in (1, 0):
+            tune(10, mode)
+            for _ in range(3):
                 got = fn()
                 torch.cuda.synchronize()
-                assert torch.equal(ref, got), (name, M, dt, mode, align, narrow)
+                assert torch.equal(ref, got), (name, M, dt, mode)
 
 
 @pytest.mark.parametrize("n_split", [1, 2])

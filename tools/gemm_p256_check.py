@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """The 256 x 256 persistent 8-phase GEMM (csrc/gemm_p256.hip) against the 128 x 128 persistent kernel: bit-equality of the
 plain / LayerNorm-fold epilogues on ragged row counts (bf16 and fp16), then interleaved timings on the per-layer shapes and on
-square problems.   python tools/gemm_p256_check.py [M ...]      (bg_tune key 10: 1 = force the 256 kernel, 2 = never; key 9:
-1 = both wave groups enter the epilogue together)"""
+square problems.   python tools/gemm_p256_check.py [M ...]      (bg_tune key 10: 0 = the 256 + 128 hybrid the library picks,
+1 = force the 256 kernel, 2 = never)"""
 import os
 import statistics
 import sys
@@ -19,8 +19,8 @@ g = torch.Generator().manual_seed(0)
 rn = lambda *s: torch.randn(*s, generator=g)
 
 
-def setv(mode, al, stg, nt, nar):
-    lib.bg_tune_set(10, mode); lib.bg_tune_set(9, al); lib.bg_tune_set(12, stg); lib.bg_tune_set(13, nt); lib.bg_tune_set(14, nar)
+def setv(mode):
+    lib.bg_tune_set(10, mode)
 
 
 TIMING = False
@@ -73,9 +73,9 @@ for dt in (torch.bfloat16, torch.float16):
             lib.bg_tune_set(10, 2)
             ref = fn().clone()
             res = []
-            for mode, al, nar, nt in ((1, 0, 0, 0), (1, 2, 1, 0), (0, 0, 0, 0), (0, 0, 1, 0)):
-                setv(mode, al, 0, nt, nar)
-                for rep in range(2):                                  # repeated: a race would not necessarily show the first time
+            for mode in (1, 0):
+                setv(mode)
+                for rep in range(3):                                  # repeated: a race would not necessarily show the first time
                     got = fn()
                     torch.cuda.synchronize()
                     res.append(torch.equal(ref, got))
@@ -86,8 +86,7 @@ for dt in (torch.bfloat16, torch.float16):
                 print(f"bit-equal {str(dt)[6:]:9s} M={M:5d} {k:12s} {ok} {res if not ok else ''} {'differing elements: %d' % nd if not ok else ''}")
 print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
 TIMING = True
-# (name, mode (key 10: 0 = hybrid 256 + 128, 1 = 256 alone, 2 = 128 alone), align (key 9: 2 = staggered wave groups), start stagger (12), nt (13), narrow (14))
-VARS = [("128", 2, 0, 0, 0, 0), ("256", 1, 0, 0, 0, 0), ("256 narrow", 1, 0, 0, 0, 1), ("hybrid", 0, 0, 0, 0, 0)]
+VARS = [("128", 2), ("256", 1), ("hybrid", 0)]
 for M in MS:
     cases = build(M, dt)
     res = {(k, v[0]): [] for k in cases for v in VARS}
@@ -114,4 +113,4 @@ for S in (4096, 8192):
         us = statistics.median(timed(fn, 10) for _ in range(3))
         line += f" | {name} {us:7.1f} {2.0 * S * S * S / us / 1e6:4.0f}"
     print(line)
-setv(0, 0, 0, 0, 0)
+setv(0)
