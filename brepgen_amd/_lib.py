@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):          # bg_gemm_desc
                 ("add", fp), ("ld_add", C.c_int), ("add_div", C.c_int),
                 ("add2", fp), ("ld_add2", C.c_int), ("add2_div", C.c_int),
                 ("out_lo", vp), ("res_hi", vp), ("res_lo", vp), ("ld_res", C.c_int),
-                ("stats_out", fp), ("stats_in", fp), ("colsum", fp), ("ln_eps", C.c_float), ("ln_coef", fp)]
+                ("stats_out", fp), ("stats_in", fp), ("colsum", fp), ("ln_eps", C.c_float)]
 
 
 BG_E_ARG, BG_E_SHAPE, BG_E_WORKSPACE, BG_E_DTYPE, BG_E_ALIGN = -1, -2, -3, -4, -5      # enum bg_err

@@ -106,7 +106,6 @@ struct GemmArgs {
     // colsum[n] = sum_k w[n,k];  out = act(rstd_m * acc - mean_m * rstd_m * colsum[n] + bias[n]) with the row
     // statistics summed from stats_in [K/64][M][2].
     const float* stats_in = nullptr; const float* colsum = nullptr; float ln_eps = 1e-5f;
-    float* ln_coef = nullptr;         // scratch [M + 2][2]: per-row (rstd, -mean * rstd) for the 256 x 256 kernel's fold (gemm_p256.hip)
     // fp32 operands, M <= 8: allow the wave-per-column GEMV (tree reduction over K instead of the MFMA's k-ordered fma
     // chain -- last-bit different, so only callers whose M never depends on the batch composition set it: the
     // time-embedding MLP)
@@ -144,7 +143,9 @@ __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = fal
         // other group's, and a tail kernel only adds a dependent launch to each chain -- the 256 kernel runs alone or not at all
         // (measured, profiles/r03/face_ldm_legs_ab_p256.log: leg B 4.17 vs 4.41 ms with the tail kernels)
         if (split) return (T >= 1024 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
-        return (T >= 400 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
+        // (non-split threshold: 300 vs 400 tiles measured on the compacted face batch, 2 x 306 QKV tiles in flight: -1.4 % per step,
+        //  profiles/r03/face_ldm_legs_ab_fold_in_kernel.log)
+        return (T >= 300 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
     }
     if (split) {
         // split-residual epilogue (out-proj / FFN2): a 256 x 256 tile spends as long in its epilogue (512 KiB of residual traffic,

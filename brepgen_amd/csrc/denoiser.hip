@@ -61,7 +61,7 @@ __global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __re
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, off_coef, off_rows, total;
+    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, off_rows, total;
     int M, F;
 };
 
@@ -78,7 +78,6 @@ static Workspace plan(int net, int B, int S, int E, int dtype) {
     w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
     w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
     w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.M * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
-    w.off_coef = o; o += (dtype != BG_F32) ? align_up((size_t)(w.M + 2) * 2 * 4) : 0;    // ... reduced to (rstd, -mean rstd) per row
     w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2) * 4) + align_up((size_t)w.M * 4) : 0;   // var-len: offsets, row map
     w.total = o;
     return w;
@@ -100,7 +99,6 @@ struct Ctx {
     void* XH = nullptr;
     void* XL = nullptr;
     float* stats = nullptr;
-    float* coef = nullptr;
     // variable-length execution: valid tokens compacted into rows 0 .. *m_dev-1 (csrc/compact.hip)
     const int* m_dev = nullptr;       // device-side row count (offsets[B])
     const int* src_row = nullptr;     // compact row -> padded-layout token index
@@ -189,7 +187,6 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         c.XH = c.X;
         c.XL = reinterpret_cast<unsigned char*>(c.X) + (size_t)M * 768 * 2;
         c.stats = reinterpret_cast<float*>(c.ws + c.p.off_stats);
-        c.coef = reinterpret_cast<float*>(c.ws + c.p.off_coef);
     }
     // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
     const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
@@ -277,7 +274,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         // x = XH + XL.  LN1 / LN2 are folded: QKV and FFN1 read the raw 16-bit rows XH and normalise in their epilogue.
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
-        qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum; qkv.ln_coef = c.coef;
+        qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
         qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
         if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
@@ -286,7 +283,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         op.m_dev = c.m_dev; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;
         if ((rc = gemm(op, c.dtype, s))) return rc;
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
-        f1.stats_in = c.stats; f1.colsum = L.w1_colsum; f1.ln_coef = c.coef;
+        f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
         f1.m_dev = c.m_dev; f1.rows_hint = c.rows_hint; f1.concurrent = c.concurrent;
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};

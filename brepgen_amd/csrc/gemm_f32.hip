@@ -148,7 +148,6 @@ extern "C" int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream) {
     g.add2 = d->add2; g.ld_add2 = d->ld_add2; g.add2_div = d->add2 ? d->add2_div : 1;
     g.out_lo = d->out_lo; g.res_hi = d->res_hi; g.res_lo = d->res_lo; g.ld_res = d->ld_res;
     g.stats_out = d->stats_out; g.stats_in = d->stats_in; g.colsum = d->colsum; g.ln_eps = d->ln_eps;
-    g.ln_coef = d->ln_coef;
     return bg::gemm(g, d->ab_dtype, (hipStream_t)stream);
 }
 

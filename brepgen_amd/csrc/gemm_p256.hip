@@ -85,6 +85,9 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds);
     const unsigned patch_lds = lds0 + (unsigned)(P256_RING + wave * P256_PATCH);
     unsigned char* patch = lds + P256_RING + wave * P256_PATCH;
+    // the four patches of a wave group (waves wm * 4 .. + 3: the same 128 rows) as one 16 KiB region (LayerNorm-fold staging)
+    const unsigned grp_lds = lds0 + (unsigned)(P256_RING + wm * 4 * P256_PATCH);
+    const unsigned char* grp = lds + P256_RING + wm * 4 * P256_PATCH;
     const bool has_bias = g.bias != nullptr;
 
     // ---- LDS-DMA: wave w moves pieces w and w + 8 (8 rows x 128 B each) of every 128-row half-tile ----
@@ -122,27 +125,38 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     }
     const unsigned w_half = 128u * ldw_b;                         // W rows 128-255: the same lane offsets on a shifted base
 
-    // Epilogue operands wait in the wave's patch while the K loop runs (no registers): [0, 1K) the tile's 256 bias values, [1K, 2K)
-    // its 256 column sums (LayerNorm fold), [2.5K, 3.5K) the (rstd, -mean rstd) pairs of the wave's 128 rows -- one 1 KiB LDS-DMA
-    // piece each, issued at the END of the previous tile's epilogue (here: in the prologue) and read into registers before the first
-    // pass of this tile's epilogue overwrites the patch.  An L2 round trip per tile would otherwise sit in front of every epilogue,
-    // and a plain load there would make hipcc wait for vmcnt(0), i.e. for the next tile's DMA as well.
+    // Epilogue operands wait in LDS while the K loop runs (no registers): one 1 KiB LDS-DMA piece each, issued at the END of the
+    // previous tile's epilogue (here: in the prologue) and read into registers before the first pass of this tile's epilogue
+    // overwrites the patches.  An L2 round trip per tile would otherwise sit in front of every epilogue, and a plain load there would
+    // make hipcc wait for vmcnt(0), i.e. for the next tile's DMA as well.
+    //   plain / split: the tile's 256 bias values in [0, 1K) of the wave's own patch.
+    //   LayerNorm fold: the four waves of a group (same 128 rows) share one copy in the group's 16 KiB -- [0, 12K) the twelve
+    //   (sum, sum of squares) partials of the 128 rows (1 KiB per 64-column part; wave wn brings parts 3 wn .. 3 wn + 2),
+    //   [12K, 13K) bias (wave 0), [13K, 14K) column sums (wave 1).  What a sibling staged is visible after the K loop's barriers
+    //   (each wave's counted vmcnt wait precedes them); two extra workgroup barriers per tile keep the region from being
+    //   overwritten by a pass while a sibling still reads it, and by the next staging while a sibling's pass still uses it.
+    //   (A 16-byte DMA element = the pairs of two rows: the launcher sends odd M / unaligned statistics to the 128 x 128 kernel.)
     auto stage_cols = [&](int n0c) {
         const unsigned voff = (unsigned)opaque(threadIdx.x & 63) * 16u;
-        if (has_bias) dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), voff);
-        if (FOLD) dma(patch_lds + 1024u, reinterpret_cast<const unsigned char*>(g.colsum + n0c), voff);
+        if constexpr (FOLD) {
+            if (wn == 0) dma(grp_lds + 12288u, reinterpret_cast<const unsigned char*>(g.bias + n0c), voff);
+            if (wn == 1) dma(grp_lds + 13312u, reinterpret_cast<const unsigned char*>(g.colsum + n0c), voff);
+        } else {
+            if (has_bias) dma(patch_lds, reinterpret_cast<const unsigned char*>(g.bias + n0c), voff);
+        }
     };
-    // LayerNorm fold: the (rstd, -mean * rstd) pairs of the wave's 128 rows come from g.ln_coef (one pair per row, written by
-    // ln_coef_kernel ahead of this launch) as one 1 KiB LDS-DMA piece, like the column vectors.  (The row statistics themselves
-    // -- 12 partial pairs per row -- cannot be summed here without cost: loads issued from the epilogue share the vector-memory
-    // counter with its stores, and the two classes retire out of order, so waiting for such a load means waiting for the stores.)
     auto stage_rows = [&](int m0t) {
-        if (FOLD) {
+        if constexpr (FOLD) {
             const int ln = opaque(threadIdx.x & 63);
-            int pair = ((m0t + wm * 128) >> 1) + ln;              // 16 bytes = the pairs of two rows
+            int pair = ((m0t + wm * 128) >> 1) + ln;
             const int last = (Mv - 1) >> 1;                       // (rows past the end: any valid address, the result is never stored)
             pair = pair < last ? pair : last;
-            dma(patch_lds + 2560u, reinterpret_cast<const unsigned char*>(g.ln_coef), (unsigned)pair * 16u);
+            const unsigned char* sb = reinterpret_cast<const unsigned char*>(g.stats_in);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int part = wn * 3 + r;
+                dma(grp_lds + (unsigned)part * 1024u, sb + (size_t)part * (size_t)g.M * 8, (unsigned)pair * 16u);
+            }
         }
     };
 
@@ -408,17 +422,45 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                 // column sums, plus the (rstd, -mean rstd) pairs of its four rows) -- read before the first pass overwrites the patch
                 float4 bz[2][4], cs[2][4];
                 float2 cf[4];
+                if constexpr (FOLD) {
+                    // (rstd, -mean rstd) of the lane's four rows from the staged partials, in the association order of every other
+                    // kernel (tree16 + ln_fold_coeffs); then the column vectors; then every wave of the workgroup must be done
+                    // reading before any wave's first pass overwrites its patch
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int i = 0; i < 4; ++i) {
+                        float ps[16], pq[16];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned off = (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u;
-                        bz[j][q] = has_bias ? *reinterpret_cast<const float4*>(patch + off) : zero4;
-                        cs[j][q] = FOLD ? *reinterpret_cast<const float4*>(patch + 1024 + off) : zero4;
+                        for (int pp = 0; pp < 16; ++pp) {
+                            const float2 v = pp < FOLD_PARTS ? reinterpret_cast<const float2*>(grp + pp * 1024)[i * 32 + l31] : make_float2(0.f, 0.f);
+                            ps[pp] = v.x; pq[pp] = v.y;
+                        }
+                        cf[i] = ln_fold_coeffs(tree16(ps), tree16(pq), g.K, g.ln_eps);
+                        // one row's 24 partials in registers at a time (no room for more): the pair is pinned here, or hipcc sinks the
+                        // arithmetic to the pass that uses it and keeps the 24 inputs alive (spilled) until then
+                        asm volatile("" : "+v"(cf[i].x), "+v"(cf[i].y) :: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    cf[i] = FOLD ? reinterpret_cast<const float2*>(patch + 2560)[i * 32 + l31] : make_float2(1.f, 0.f);
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned off = (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u;
+                            bz[j][q] = *reinterpret_cast<const float4*>(grp + 12288 + off);
+                            cs[j][q] = *reinterpret_cast<const float4*>(grp + 13312 + off);
+                        }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    bar();
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bz[j][q] = has_bias ? *reinterpret_cast<const float4*>(patch + (unsigned)(wn * 64 + j * 32 + 8 * q + 4 * hq) * 4u) : zero4;
+                            cs[j][q] = zero4;
+                        }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cf[i] = make_float2(1.f, 0.f);
+                }
                 // patch rows of 128 B; 16-byte chunk (j*4 + q) XOR-swizzled by the row; rows 8-15 / 24-31 swap the two 8-byte
                 // halves, so the 16 lanes of a ds_write_b64 service group hit 32 distinct banks
                 const unsigned wr_base = (unsigned)l31 * 128u + (unsigned)((hq ^ ((l31 >> 3) & 1)) * 8);
@@ -443,6 +485,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
             }
             if (has_next) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the patch accesses above are complete
+                if constexpr (FOLD) bar();                         // ... those of the sibling waves too: the staging below writes into their patches
                 stage_cols(n0n);
                 stage_rows(m0n);
             }
@@ -451,22 +494,6 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
         if (wm == 1) bar();                                       // restore the one-barrier lag of waves 4-7
         L = Ln; m0 = m0n; n0 = n0n; a_cur = a_nxt; w_cur = w_nxt;
     }
-}
-
-// (sum, sum of squares) partials per 64-column group [K/64][M][2] -> (rstd, -mean * rstd) per row [M][2], in the association order
-// every kernel uses (tree16 + ln_fold_coeffs): what the LayerNorm-fold epilogue of the 256 x 256 kernel reads.  One thread per row.
-__global__ __launch_bounds__(256) void ln_coef_kernel(const float2* __restrict__ stats, float2* __restrict__ coef, int M,
-                                                       const int* __restrict__ m_dev, int K, float eps) {
-    const int Mv = m_dev ? *m_dev : M;
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= Mv) return;
-    float ps[16], pq[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const float2 v = p < FOLD_PARTS ? stats[(size_t)p * M + row] : make_float2(0.f, 0.f);
-        ps[p] = v.x; pq[p] = v.y;
-    }
-    coef[row] = ln_fold_coeffs(tree16(ps), tree16(pq), K, eps);
 }
 
 bool p256_eligible(const GemmArgs& g) {
@@ -478,7 +505,7 @@ bool p256_eligible(const GemmArgs& g) {
     if (split)          // split residual stream in place (out-proj / FFN2): residual planes required, no LayerNorm fold on top
         return !fold && g.res_hi != nullptr && g.res_lo != nullptr && g.ld_res % 8 == 0 && (size_t)g.M * g.ld_res * 2 < 0xffffffffull;
     return g.res_hi == nullptr && g.stats_out == nullptr &&
-           (!fold || (g.K == FOLD_PARTS * G_BK && g.colsum != nullptr && g.bias != nullptr && g.ln_coef != nullptr));
+           (!fold || (g.K == FOLD_PARTS * G_BK && g.colsum != nullptr && g.bias != nullptr && (g.M & 1) == 0 && ((size_t)g.stats_in & 15) == 0));
 }
 
 template <bool F16>
@@ -488,12 +515,6 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr, g.hybrid == 2) : g.M + 255) / 256) * (g.N_pad / 256);
     if (tiles == 0) return 0;
     const int grid = tiles < 256 ? tiles : 256;
-    if (g.stats_in) {                                             // LayerNorm fold: one (rstd, -mean rstd) pair per row first
-        hipLaunchKernelGGL(ln_coef_kernel, dim3((g.M + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float2*>(g.stats_in),
-                           reinterpret_cast<float2*>(g.ln_coef), g.M, g.m_dev, g.K, g.ln_eps);
-        const int rc = launch_status("ln_coef");
-        if (rc) return rc;
-    }
     if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(512), 0, s, g);
     else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(512), 0, s, g);
     else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16>), dim3(grid), dim3(512), 0, s, g);

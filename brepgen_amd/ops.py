@@ -90,8 +90,6 @@ def linear_ex(a, w, bias=None, *, act=BG_ACT_NONE, out_dtype=None, add=None, add
         d.stats_out = ptr(r["stats"])
     if stats_in is not None:
         d.stats_in, d.colsum = ptr(stats_in.contiguous()), ptr(colsum.contiguous())
-        r["_coef"] = torch.empty(M + 2, 2, device=a.device, dtype=torch.float32)     # scratch for the 256 x 256 kernel's fold
-        d.ln_coef = ptr(r["_coef"])
     d.ln_eps = ln_eps
     r["_keep"] = (a, w, bias, add, add2, res, stats_in, colsum)
     check(_lib.load().bg_gemm_ex_fwd(d, stream()), "bg_gemm_ex_fwd")

@@ -74,10 +74,9 @@ int bg_gemm_bias_act_fwd(const void* a, int lda, const void* w, const float* bia
  *   stats_in, colsum  LayerNorm fold: a holds raw (un-normalised) 16-bit rows, w = T(gamma * W), bias = b + W beta,
  *                   colsum[n] = sum_k w[n,k]; the epilogue computes act(rstd_m * acc - mean_m * rstd_m * colsum[n] +
  *                   bias[n]) with mean / rstd summed from stats_in [K/64][M][2] (written by a producer's stats_out).
- *   ln_coef         optional scratch of 2 * (M + 2) floats for the LayerNorm fold: when given, launches large enough for the
- *                   256 x 256 persistent kernel first reduce stats_in to one (rstd, -mean * rstd) pair per row there (one
- *                   tiny extra launch) and the GEMM fetches a tile's pairs with its LDS-DMA stream; without it the fold always
- *                   runs on the 128 x 128 kernel, which sums the partials in its epilogue.  Same bits either way.
+ *                   (Launches large enough for the 256 x 256 persistent kernel take it when M is even and stats_in is
+ *                   16-byte aligned -- it fetches the partials with its LDS-DMA stream, two rows per element; otherwise the
+ *                   128 x 128 kernel runs.  Same bits either way.)
  * The new options need ab_dtype BG_BF16 | BG_F16, N == N_pad and ldc % 8 == 0. */
 typedef struct {
     const void* a; int lda;
@@ -91,7 +90,6 @@ typedef struct {
     const void* res_hi; const void* res_lo; int ld_res;
     float* stats_out;
     const float* stats_in; const float* colsum; float ln_eps;
-    float* ln_coef;
 } bg_gemm_desc;
 int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
 

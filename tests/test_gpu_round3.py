@@ -65,11 +65,12 @@ def _gemm_cases(M, dt, seed=0):
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
-@pytest.mark.parametrize("M", [1037, 256 * 7, 129, 17293])
+@pytest.mark.parametrize("M", [1037, 1038, 256 * 7, 130, 17294])
 def test_p256_gemm_is_bit_identical_to_the_128_kernel(pc, tune, dt, M):
     """Plain and LayerNorm-fold epilogues, ragged row counts, the 256 kernel alone (key 10 = 1) and as the 256 + 128 hybrid
-    (key 10 = 0; at M = 17 293 the QKV launch splits into two full rounds on the 256 kernel + 11 row panels on the 128
-    kernel).  Repeated: a race in the 8-phase K loop would not necessarily show the first time."""
+    (key 10 = 0; at M = 17 294 the QKV launch splits into two full rounds on the 256 kernel + 12 row panels on the 128
+    kernel).  Odd M: the fold launches stay on the 128 kernel (the 256 kernel fetches the row statistics two rows per DMA
+    element).  Repeated: a race in the 8-phase K loop would not necessarily show the first time."""
     for name, fn in _gemm_cases(M, dt).items():
         tune(10, 2)
         ref = fn().clone()

@@ -68,7 +68,7 @@ def timed(fn, n=20):
 
 bad = 0
 for dt in (torch.bfloat16, torch.float16):
-    for M in (1037, 256 * 7, 4999, 17293, 30720 + 77):
+    for M in (1037, 1038, 256 * 7, 4999, 17294, 30720 + 78):
         for k, (fn, N, K) in build(M, dt).items():
             lib.bg_tune_set(10, 2)
             ref = fn().clone()
@@ -81,7 +81,7 @@ for dt in (torch.bfloat16, torch.float16):
                     res.append(torch.equal(ref, got))
             ok = all(res)
             bad += not ok
-            if not ok or M == 1037:
+            if not ok or M == 1038:
                 nd = (ref != got).sum().item()
                 print(f"bit-equal {str(dt)[6:]:9s} M={M:5d} {k:12s} {ok} {res if not ok else ''} {'differing elements: %d' % nd if not ok else ''}")
 print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)")
