@@ -889,10 +889,11 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         // phase offset of the second workgroup of every CU (bg_tune key 8: sleep units of 64 cycles; 0 = off), only when a
         // workgroup walks enough tiles for the one-off delay to pay
         const int stg = (grid == 512 && nt >= 4 * 512) ? g_tune[TUNE_GEMM_STAGGER] : 0;
-        if (variant == 31 && g.out_lo == nullptr && g.stats_in == nullptr) {   // s_memtime phase accounting (tools/gemm_instr.py)
+        if (variant == 31 && g.stats_in == nullptr) {             // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
+            if (g.out_lo) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
+            else if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
             else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);

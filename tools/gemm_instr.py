@@ -16,20 +16,34 @@ def s32(v):
     return v - (1 << 32) if v >= (1 << 31) else v
 lib.bg_tune_set(1, s32(p))
 lib.bg_tune_set(2, s32(p >> 32))
-for name, N, K, mode in [("qkv", 2304, 768, "bf16"), ("outproj", 768, 768, "resid"), ("ffn1", 1024, 768, "bf16"), ("ffn2", 768, 1024, "resid")]:
+M = int(sys.argv[1]) if len(sys.argv) > 1 else M
+for name, N, K, mode in [("qkv", 2304, 768, "bf16"), ("outproj", 768, 768, "resid"), ("ffn1", 1024, 768, "bf16"), ("ffn2", 768, 1024, "resid"),
+                         ("outproj split", 768, 768, "split"), ("ffn2 split", 768, 1024, "split")]:
     a = torch.randn(M, K, generator=g).cuda().to(BF16)
     w = (torch.randn(N, K, generator=g) / 28).cuda().to(BF16)
     b = torch.randn(N, generator=g).cuda()
     out = torch.zeros(M, N, device="cuda", dtype=BF16 if mode == "bf16" else F32)
+    hi, lo = torch.randn(M, N, device="cuda").to(BF16), (torch.randn(M, N, device="cuda") * 1e-3).to(BF16)
+
+    def run():
+        if mode == "bf16":
+            ops.linear(a, w, b, out=out)
+        elif mode == "resid":
+            ops.linear(a, w, b, add=out, out=out)
+        else:                                                         # split residual stream + row statistics (out-proj / FFN2 of the denoisers)
+            ops.linear_ex(a, w, b, split_out=True, res=(hi, lo), want_stats=True)
     lib.bg_tune_set(0, 30)
     for _ in range(3):
-        ops.linear(a, w, b, out=out) if mode == "bf16" else ops.linear(a, w, b, add=out, out=out)
+        run()
     torch.cuda.synchronize()
     lib.bg_tune_set(0, 31)
     dbg.zero_()
+    run()                                                             # (allocations of linear_ex outside the timed launch)
+    torch.cuda.synchronize()
+    dbg.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.linear(a, w, b, out=out) if mode == "bf16" else ops.linear(a, w, b, add=out, out=out)
+    run()
     e1.record()
     torch.cuda.synchronize()
     d = dbg.cpu().reshape(512, 4, 8).double()
