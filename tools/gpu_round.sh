@@ -8,7 +8,7 @@ mkdir -p $O
 cd $R
 WHAT=${1:-all}
 if [[ $WHAT == all || $WHAT == test ]]; then
-  timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  timeout 1300 python -m pytest tests -m gpu -q --durations=25 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
   tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log
 fi
