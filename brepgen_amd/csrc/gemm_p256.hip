@@ -3,6 +3,7 @@
 //
 //   out[m,n] = act(sum_k a[m,k] * w[n,k] + bias[n])          (P_PLAIN16)
 //   out[m,n] = act(rstd_m * acc - mean_m rstd_m colsum[n] + bias[n])   (P_FOLD16: a = raw residual rows, see gemm_16bit.hip)
+//   (hi, lo)[m,n] = split(acc + bias[n] + res_hi[m,n] + res_lo[m,n]), row statistics per 64 columns   (P_SPLIT: out-proj / FFN2, in place)
 //
 // Why a second kernel next to the 128 x 128 persistent one (gemm_16bit.hip): that kernel's K loop needs 512 B of LDS-DMA per MFMA and
 // tops out at ~0.3 of the MFMA peak; a 256 x 256 tile needs 256 B per MFMA, and the 8-phase schedule of the CDNA programming guide
@@ -19,8 +20,9 @@
 //     (tools/mfma_swap_probe.hip, profiles/r03/mfma_swap_probe.log) and the k order is that of every other GEMM kernel here, so
 //     results stay bit-identical to theirs (tests/test_gpu_round3.py);
 //   * epilogue: accumulators -> 16-bit -> a wave-private 4 KiB LDS patch (conflict-free both ways: 16-byte XOR swizzle + a
-//     half swap on odd row octets) -> 16-byte stores of whole 128-byte output lines.  The patch does not alias the ring, no
-//     workgroup barrier is involved.
+//     half swap on odd row octets) -> 16-byte stores of whole 128-byte output lines.  The patch does not alias the ring; no
+//     workgroup barrier is involved except in the LayerNorm fold, whose row statistics the four waves of a row group stage
+//     for each other (two barriers per tile, see stage_cols / stage_rows).
 //
 // K loop (validated as `variant 7` of the generic kernel before it moved here).  Tile = 8 waves as 2 (rows) x 4 (columns), 128 x 64
 // per wave = 4 x 2 MFMA tiles.  Two 64 KiB buffers (K-steps t, t+1), each four 16 KiB half-tiles: A rows 0-127 / 128-255, W rows
