@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """In-process A/B of bg_tune settings on the three face-LDM loops of bench.py (one box, one process, interleaved rounds):
-    python tools/face_ldm_ab.py "10=2" "10=0" "10=0,11=480" ...        each argument = one setting (key=value,...)"""
+    python tools/face_ldm_ab.py "10=2" "10=0" ...        each argument = one setting (key=value,...); BG_SPLITS=1,2,4: the n_split values"""
 import os
 import statistics
 import sys
@@ -38,7 +38,7 @@ def clock(ks):
     return (time.perf_counter() - t0) / sum(ks) * 1e3
 
 
-for split in (1, 2):
+for split in [int(v) for v in os.environ.get("BG_SPLITS", "1,2").split(",")]:
     ldm.set_split(split)
     res = {(s, leg): [] for s in SETTINGS for leg in "ABC"}
     for r in range(ROUNDS):
