@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int KT = g.K / G_BK;
 
     int m0, n0;
-    unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0;
+    unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0, t_e0 = 0, t_e1 = 0, hw_id = 0;
     if (INSTR) t_begin = __builtin_amdgcn_s_memtime();
     // walk 2 (A/B knob): workgroups w and w + cnt/2 of an XCD -- observed to share a CU (tools/cu_census.hip) -- take
     // ADJACENT column tiles of one row panel, so the partner's A lines are already in the CU's vector L1
@@ -781,13 +781,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     __builtin_amdgcn_wave_barrier();
                 }
         }
-        if (INSTR) { t_epi += __builtin_amdgcn_s_memtime() - te; ++n_done; }
+        if (INSTR) {
+            if (n_done == 0) t_e0 = te;                           // when the first / second epilogue of this workgroup began
+            if (n_done == 1) t_e1 = te;
+            t_epi += __builtin_amdgcn_s_memtime() - te; ++n_done;
+        }
         if (!has_next) break;
     }
     if (INSTR && dbg != nullptr && lane == 0) {
         unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
         o[0] = t_wait; o[1] = t_comp; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime() - t_begin; o[4] = n_done;
-        o[5] = t_begin;
+        o[5] = t_begin; o[6] = t_e0; o[7] = t_e1;
     }
 }
 
@@ -892,9 +896,9 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (variant == 31 && g.stats_in == nullptr) {             // s_memtime phase accounting (tools/gemm_instr.py)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
                 ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            if (g.out_lo) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
-            else if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
-            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg);
+            if (g.out_lo) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
+            else if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
+            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.out_lo) {

@@ -17,6 +17,9 @@ def s32(v):
 lib.bg_tune_set(1, s32(p))
 lib.bg_tune_set(2, s32(p >> 32))
 M = int(sys.argv[1]) if len(sys.argv) > 1 else M
+if len(sys.argv) > 2:
+    lib.bg_tune_set(8, int(sys.argv[2]))          # start offset of the second workgroup of every CU, units of 64 cycles
+    print(f"phase offset knob (bg_tune 8) = {sys.argv[2]}")
 for name, N, K, mode in [("qkv", 2304, 768, "bf16"), ("outproj", 768, 768, "resid"), ("ffn1", 1024, 768, "bf16"), ("ffn2", 768, 1024, "resid"),
                          ("outproj split", 768, 768, "split"), ("ffn2 split", 768, 1024, "split")]:
     a = torch.randn(M, K, generator=g).cuda().to(BF16)
@@ -49,8 +52,20 @@ for name, N, K, mode in [("qkv", 2304, 768, "bf16"), ("outproj", 768, 768, "resi
     d = dbg.cpu().reshape(512, 4, 8).double()
     us = e0.elapsed_time(e1) * 1000
     tot = d[:, :, 3]
-    span = (d[:, :, 5] + d[:, :, 3]).max() - d[:, :, 5][d[:, :, 5] > 0].min()
+    ran = d[:, :, 5] > 0
+    span = (d[:, :, 5] + d[:, :, 3])[ran].max() - d[:, :, 5][ran].min()
+    # phase relation of the two workgroups that share a CU (blocks b and b + G/2: tools/cu_census.hip): the offset between the
+    # starts of their first epilogues, as a fraction of a tile's duration -- 0 = in lock-step (the epilogue traffic of one
+    # never runs under the K loop of the other), 0.5 = perfectly interleaved
+    G = int((d[:, 0, 4] > 0).sum())
+    if G >= 2 and G % 2 == 0:
+        e0 = d[:G, 0, 6]
+        tile = (tot[:G, 0] / d[:G, 0, 4].clamp(min=1)).mean()
+        off = (e0[: G // 2] - e0[G // 2:]).abs() / tile
+        print(f"  co-resident pairs: |first-epilogue offset| / tile time: median {off.median():.3f}, mean {off.mean():.3f}, "
+              f"90th pct {off.kthvalue(max(1, int(0.9 * off.numel()))).values:.3f}  (tile = {tile:.0f} ticks)")
     print(f"{name}: kernel {us:.1f} us; per-wave cycles avg: total {tot.mean():.0f} (max {tot.max():.0f}) "
           f"wait+barrier {d[:,:,0].mean():.0f} compute {d[:,:,1].mean():.0f} epilogue {d[:,:,2].mean():.0f} "
-          f"tiles/wg {d[:,:,4].mean():.2f}; span {span:.0f} cyc -> clock {span/us:.0f} MHz(memtime ticks/us)", flush=True)
+          f"tiles/wg {d[:,:,4][ran].mean():.2f}; span {span:.0f} ticks -> {span/us:.0f} memtime ticks/us", flush=True)
 lib.bg_tune_set(0, 0)
+lib.bg_tune_set(8, 0)
