@@ -330,10 +330,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   P_SPLIT    split (hi, lo) output, addend = split residual or fp32 broadcast rows, optional row statistics
 //                                                                       -- out-proj / FFN2 / token embeds of the denoisers
 
-template <bool F16, int MODE, bool INSTR, bool CONV = false>      // CONV: the A operand is gathered from a conv window (implicit GEMM)
+// CONV: the A operand is gathered from a conv window (implicit GEMM).  PURE (P_SPLIT only): the residual-stream form of the denoiser
+// layers -- split residual in, (hi, lo) + row statistics out, no activation, no broadcast addends, no row map -- with the
+// epilogue's run-time option checks folded away (same arithmetic, fewer instructions on the epilogue's latency chain).
+template <bool F16, int MODE, bool INSTR, bool CONV = false, bool PURE = false>
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg,
                                                                    int stagger = 0) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
+    static_assert(!PURE || SPLIT, "PURE specialises the split-residual epilogue");
+    const bool k_relu = PURE ? false : g.act == BG_ACT_RELU, k_res_split = PURE ? true : g.res_hi != nullptr;
+    const bool k_add2 = PURE ? false : g.add2 != nullptr, k_stats = PURE ? true : g.stats_out != nullptr;
+    const bool k_map = PURE ? false : g.row_map != nullptr;
     using E = Elem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 
     unsigned* patch = reinterpret_cast<unsigned*>(lds + RING + wave * 4096);
     constexpr bool half_fast = FAST;
-    const bool has_res = !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
+    const bool has_res = PURE ? true : !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
     const int KT = g.K / G_BK;
 
     int m0, n0;
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         // half it -> row rbase + 16 t + 8 it + lane / 8) are requested at the START of the tile, a whole K loop ahead of
         // the residual prefetch that depends on them.
         int ridx[8];
-        if (SPLIT && g.row_map != nullptr) {
+        if (SPLIT && k_map) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 int grow = rbase + k * 8 + (lane >> 3);
@@ -509,10 +516,10 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     // two 16-byte loads either way (hi / lo octets, or 8 fp32 addends): select the ADDRESSES, so the
                     // loads themselves stay unconditional and in flight together
                     const size_t o = (size_t)grow * g.ld_res + cbase + (lane & 7) * 8;
-                    const int arow = (g.row_map != nullptr && g.map_add) ? ridx[t * 2 + it] : grow;
-                    const float* ap = g.add + (size_t)(arow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
-                    const void* p0 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_hi) + o) : (const void*)ap;
-                    const void* p1 = g.res_hi ? (const void*)(reinterpret_cast<const T*>(g.res_lo) + o) : (const void*)(ap + 4);
+                    const int arow = (k_map && g.map_add) ? ridx[t * 2 + it] : grow;
+                    const float* ap = PURE ? nullptr : g.add + (size_t)(arow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
+                    const void* p0 = k_res_split ? (const void*)(reinterpret_cast<const T*>(g.res_hi) + o) : (const void*)ap;
+                    const void* p1 = k_res_split ? (const void*)(reinterpret_cast<const T*>(g.res_lo) + o) : (const void*)(ap + 4);
                     res[buf][2 * it] = *reinterpret_cast<const float4*>(p0);
                     res[buf][2 * it + 1] = *reinterpret_cast<const float4*>(p1);
                 }
@@ -681,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
                     for (int rr = 0; rr < 8; ++rr) {
                         float v = acc[i][j][half * 8 + rr] + bias_l[j];
-                        if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (k_relu) v = fmaxf(v, 0.f);
                         pf[((rr & 3) + 8 * (rr >> 2) + 4 * h) * 64 + j * 32 + (lane & 31)] = v;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     const bool row_ok = grow < Mv;
                     if (has_res) {
                         const float4 r0 = res[t & 1][2 * it], r1 = res[t & 1][2 * it + 1];
-                        if (g.res_hi) {                           // x_old = hi + lo
+                        if (k_res_split) {                        // x_old = hi + lo
                             float fh[4], fl[4];
                             unpack4_16<F16>(make_uint2(__float_as_uint(r0.x), __float_as_uint(r0.y)), fh);
                             unpack4_16<F16>(make_uint2(__float_as_uint(r1.x), __float_as_uint(r1.y)), fl);
@@ -711,14 +718,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                             v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
                         }
                     }
-                    if (g.add2) {
-                        const int crow = (g.row_map != nullptr && g.map_add2) ? ridx[t * 2 + it] : (row_ok ? grow : Mv - 1);
+                    if (k_add2) {
+                        const int crow = (k_map && g.map_add2) ? ridx[t * 2 + it] : (row_ok ? grow : Mv - 1);
                         const float* ap = g.add2 + (size_t)(crow / g.add2_div) * g.ld_add2 + gcol;
                         const float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 4);
                         v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w;
                         v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
                     }
-                    if (g.stats_out) {
+                    if (k_stats) {
                         // same association order as the generic kernel: 4-column chunk partials, then a butterfly
                         const float s8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                         const float q8 = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
@@ -901,6 +908,9 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
             else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+        } else if (g.out_lo && g.res_hi && g.stats_out && !g.add && !g.add2 && !g.row_map && g.act == BG_ACT_NONE && g_tune[14] != 1) {
+            // the residual-stream GEMMs of the denoiser layers (bg_tune key 14 = 1: the general split instantiation, for A/B)
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.out_lo) {
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.stats_in) {
