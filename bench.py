@@ -246,7 +246,7 @@ def edge_net_extra(dev, evals=2):
 class FaceLDM:
     """The three loops of the face LDM on the HIP path (one rank's 512 samples), each an endless step generator."""
 
-    def __init__(self, dev, rank, dense=False, split=0):
+    def __init__(self, dev, rank, dense=False, split=0, dtype=torch.bfloat16):
         import brepgen_amd as bga
         from brepgen_amd.sampling import device_randn
         torch.manual_seed(0)
@@ -254,7 +254,7 @@ class FaceLDM:
         self.pos_net = bga.SurfPosNet(False).to(dev).eval()
         self.z_net = bga.SurfZNet(False).to(dev).eval()
         for n in (self.pos_net, self.z_net):
-            n.compute_dtype = torch.bfloat16
+            n.compute_dtype = dtype
             if split:
                 n.n_split = split
         self.z_net.cache_conditioning = False     # every step recomputes p_embed(surfPos) like the reference does (network.py:1182)
@@ -336,16 +336,30 @@ def cascade_extra():
     return cascade_bench.run(256)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    written by tools/pmc_summary.py: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2
-    is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).  None when no measurement is committed."""
+def rank_local_extra(name, k=3):
+    """BASELINE configs[3] / configs[4] as one rank runs them (tools/rank_local_bench.py): K iterations of each of the four
+    cascade loops at the rank-local batch, per-iteration times and the projected full loops."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rank_local_bench
+    return rank_local_bench.run(name, k)
+
+
+def pmc_traffic(kernel, launches_per_step):
+    """Fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
+    by tools/pmc_summary.py from `bench.py --steps 40 --warmup 3 --split 1` under --pmc FETCH_SIZE / WRITE_SIZE: (2 x FETCH_SIZE
+    + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).
+    A stored measurement is only comparable with this run's algorithmic bytes when it was taken on the same step mix: the file
+    records the kernel's launches per step of ITS run, and a mismatch of more than 5 % with this run's returns None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel.split("(")[0], {}).get("bytes_per_launch")
-    except OSError:
-        return None
+            row = json.load(f).get(kernel.split("(")[0], {})
+    except (OSError, ValueError):
+        return None, None
+    lps = row.get("launches_per_step")
+    if not row.get("bytes_per_launch") or not lps or abs(lps - launches_per_step) > 0.05 * launches_per_step:
+        return None, None
+    return row["bytes_per_launch"], row.get("measured_on")
 
 
 def main():
@@ -481,6 +495,25 @@ def main():
             d = clock(0, 0, 20)
             extra["dense_execution_loop_C"] = {"ms_per_step": round(1e3 * d / 20, 4), "steps_per_s_per_gpu": round(20 / d, 3)}
             ldm.z_net.varlen, ldm.z_net.profile_hints = True, hints
+            # the composite on the DENSE definition of a step (every padded position computed, as the reference runs
+            # loop C): the per-loop times above, weighted 158 : 250 : 209
+            tot_w = sum(w for _, _, w in LEGS)
+            ms_dense = (LEGS[0][2] * legs["A"]["ms_per_step"] + LEGS[1][2] * legs["B"]["ms_per_step"] +
+                        LEGS[2][2] * extra["dense_execution_loop_C"]["ms_per_step"]) / tot_w
+            extra["dense_definition_composite"] = {"ms_per_step": round(ms_dense, 4), "steps_per_s_per_gpu": round(1e3 / ms_dense, 2),
+                                                   "from": "face_ldm_legs A, B + dense_execution_loop_C (20 iterations each)"}
+        # the same three loops with fp16 operands -- the autocast dtype the reference itself runs (sample.py:121) and the drop-in
+        # modules' default inside torch.autocast('cuda')
+        ldm16 = FaceLDM(dev, rank, dense=args.dense, split=args.split, dtype=torch.float16)
+        ldm16.run(1, 1, 1)
+        barrier()
+        t1 = time.perf_counter()
+        ldm16.run(*split_steps(20))
+        barrier()
+        d = time.perf_counter() - t1
+        extra["fp16_operands_composite"] = {"ms_per_step": round(1e3 * d / 20, 4), "steps_per_s_per_gpu": round(20 / d, 2),
+                                            "steps_per_loop": dict(zip("ABC", split_steps(20)))}
+        del ldm16
 
     roofline = None
     breakdown = None
@@ -500,8 +533,11 @@ def main():
                          "gbs": round(r["bytes"] / r["total_ms"] / 1e6, 1)} for k, r in rows.items()}
         dom = max(rows.values(), key=lambda r: r["total_ms"])
         ach = dom["flops"] / dom["total_ms"] / 1e9                    # TFLOP/s = flops per launch / avg duration
+        traffic, traffic_src = pmc_traffic(dom["kernel"], dom["launches"] / args.steps)
         roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
+                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_over_algorithmic_bytes": round(traffic / (dom["bytes"] / dom["launches"]), 3) if traffic else None,
+                    "traffic_measured_on": traffic_src,
                     "launches_per_step": round(dom["launches"] / args.steps, 2),
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],
@@ -524,6 +560,11 @@ def main():
             extra["cascade_cfg3"] = cascade_extra()
         except Exception as e:                                       # reported, never fatal for the headline
             extra["cascade_cfg3"] = {"error": repr(e)}
+        for name in ("cfg4", "cfg5"):
+            try:
+                extra["rank_local_" + name] = rank_local_extra(name)
+            except Exception as e:
+                extra["rank_local_" + name] = {"error": repr(e)}
 
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
@@ -532,6 +573,8 @@ def main():
             "metric": "denoising-steps/sec (whole node), DeepCAD face-LDM, batch=512",
             "value": round(steps_per_s, 3), "unit": "denoising-steps/s (batch=512 per step)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value_dense": (round(world * extra["dense_definition_composite"]["steps_per_s_per_gpu"], 3)
+                            if "dense_definition_composite" in extra else None),
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DeepCAD face-LDM = the three loops of sample.py:126-202, step-weighted: "

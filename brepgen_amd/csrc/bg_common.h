@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -34,7 +34,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 };
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
-enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_COUNT = 16 };
+enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -117,7 +117,7 @@ struct GemmArgs {
     const int* m_dev = nullptr;
     const int* row_map = nullptr;
     int map_add = 0, map_add2 = 0, map_out = 0;
-    double rows_hint = 0.0;           // expected *m_dev, used only by the opt-in profiler's FLOP / byte accounting
+    double rows_hint = 0.0;           // host-side estimate of *m_dev (0 = unknown): kernel choice in launch16 + profiler accounting
     // ---- implicit-GEMM convolution (16-bit operands, persistent kernel only; csrc/gemm_16bit.hip) ----
     // cv_C > 0: `a` is a channels-last activation tensor [S, H, W, C] (already normalised / activated), row m of the GEMM is
     // output pixel (s, oy, ox) of the 'same' stride-1 convolution on the nearest-upsampled grid (H << up, W << up), and

@@ -35,7 +35,8 @@ ProfRec* g_recs = nullptr;
 int g_cap = 0, g_n = 0;
 bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(128x64)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
-                                          "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)"};
+                                          "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
+                                          "gemm16_split_pipe_kernel(128x128)"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {
@@ -104,7 +105,7 @@ struct Ctx {
     const int* src_row = nullptr;     // compact row -> padded-layout token index
     const int* offsets = nullptr;     // per-sample first row, [B+1]
     int N_tok = 1;                    // tokens per sample of the padded layout
-    double rows_hint = 0.0, pairs_hint = 0.0;
+    double rows_hint = 0.0, pairs_hint = 0.0;   // host-side estimates: GEMM kernel choice + profiler accounting (brepgen_hip.h)
     int concurrent = 0;               // sibling sample groups are in flight on forked streams (n_split > 1)
 };
 
@@ -155,8 +156,10 @@ static int embed_mlp(Ctx& c, const bg_mlp_weights& m, const void* x, int lda, in
     return gemm(g2, c.dtype, c.s);
 }
 
+// concurrent: sibling sample groups of the same call are in flight on forked streams (tells the GEMM launcher that a partial
+// round of tiles will be filled by the other group: bg_common.h p256_rows)
 static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float* eps_out, void* workspace,
-               size_t ws_bytes, hipStream_t s) {
+               size_t ws_bytes, hipStream_t s, bool concurrent = false) {
     const int net = w->net, B = in->B, S = in->S, E = (net >= BG_EDGEPOS) ? in->E : 1;
     BG_REQUIRE(net >= BG_SURFPOS && net <= BG_EDGEZ, BG_E_ARG, "bg_denoiser_fwd: bad net id %d", net);
     BG_REQUIRE(w->dtype == BG_BF16 || w->dtype == BG_F16 || w->dtype == BG_F32, BG_E_DTYPE, "bg_denoiser_fwd: compute dtype %d", w->dtype);
@@ -191,7 +194,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
     const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
     c.N_tok = N;
-    c.concurrent = in->n_split < 0;
+    c.concurrent = concurrent ? 1 : 0;
     if (varlen) {
         int* offs = reinterpret_cast<int*>(c.ws + c.p.off_rows);
         int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2) * 4));
@@ -439,6 +442,7 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
     using namespace bg;
     BG_REQUIRE(w && in, BG_E_ARG, "bg_denoiser_fwd: null descriptor");
     hipStream_t s = (hipStream_t)stream;
+    BG_REQUIRE(in->n_split >= 0, BG_E_ARG, "bg_denoiser_fwd: n_split must be >= 0 (got %d)", in->n_split);
     const int ns = in->n_split > MAX_SPLIT ? MAX_SPLIT : in->n_split;
     if (ns < 2 || in->B < ns) return run(w, in, eps_out, workspace, workspace_bytes, s);
 
@@ -467,7 +471,7 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
         split_range(in->B, ns, k, lo, hi);
         bg_denoiser_inputs sub = *in;
         sub.B = hi - lo;
-        sub.n_split = -1;                                         // (a sub-run: tells run() that sibling groups are in flight)
+        sub.n_split = 1;
         sub.x = in->x + (size_t)lo * tok * kInCols[net];
         if (in->surf_pos) sub.surf_pos = in->surf_pos + (size_t)lo * S * 6;
         if (in->surf_z) sub.surf_z = in->surf_z + (size_t)lo * S * 48;
@@ -476,12 +480,12 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
         if (in->n_timesteps == in->B) { sub.timesteps = in->timesteps + lo; sub.n_timesteps = sub.B; }
         if (in->class_label) sub.class_label = in->class_label + lo;
         if (in->cond_cache) sub.cond_cache = in->cond_cache + (size_t)lo * S * 768;
-        sub.rows_hint = in->rows_hint * sub.B / in->B;            // profiler accounting only: proportional share
+        sub.rows_hint = in->rows_hint * sub.B / in->B;            // estimates: proportional share
         sub.pairs_hint = in->pairs_hint * sub.B / in->B;
         const size_t bytes = align_up(plan(net, sub.B, S, E, w->dtype).total);
         hipStream_t sk = k == 0 ? s : g_split.aux[k - 1];
         if (k > 0 && (he = hipStreamWaitEvent(sk, g_split.fork, 0)) != hipSuccess) { rc = (int)he; break; }
-        rc = run(w, &sub, eps_out + (size_t)lo * tok * w->fc_out.n_out, wsp, bytes, sk);
+        rc = run(w, &sub, eps_out + (size_t)lo * tok * w->fc_out.n_out, wsp, bytes, sk, /*concurrent=*/true);
         if (rc) break;
         wsp += bytes;
     }

@@ -44,4 +44,8 @@ constexpr int FOLD_PARTS = 12;      // the persistent kernels' LayerNorm fold is
 bool p256_eligible(const GemmArgs& g);
 template <bool F16> int launch_p256(const GemmArgs& g, hipStream_t s);
 
+// software-pipelined split-residual kernel (gemm_split.hip): out-proj / FFN2 of the encoder layers
+bool split_pipe_eligible(const GemmArgs& g);
+template <bool F16> int launch_split_pipe(const GemmArgs& g, hipStream_t s);
+
 }  // namespace bg

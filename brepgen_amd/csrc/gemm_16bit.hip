@@ -337,7 +337,7 @@ template <bool F16, int MODE, bool INSTR, bool CONV = false, bool PURE = false>
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg,
                                                                    int stagger = 0) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
-    static_assert(!PURE || SPLIT, "PURE specialises the split-residual epilogue");
+    static_assert(!PURE || SPLIT || CONV, "PURE specialises the split-residual epilogue and the convolution epilogue (fp32 out, no activation, add_div 1, no add2)");
     const bool k_relu = PURE ? false : g.act == BG_ACT_RELU, k_res_split = PURE ? true : g.res_hi != nullptr;
     const bool k_add2 = PURE ? false : g.add2 != nullptr, k_stats = PURE ? true : g.stats_out != nullptr;
     const bool k_map = PURE ? false : g.row_map != nullptr;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 
     unsigned* patch = reinterpret_cast<unsigned*>(lds + RING + wave * 4096);
     constexpr bool half_fast = FAST;
-    const bool has_res = PURE ? true : !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
+    const bool has_res = (PURE && SPLIT) ? true : !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
     const int KT = g.K / G_BK;
 
     int m0, n0;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 int grow = rbase + i * 32 + it * 8 + (lane >> 3);
                 grow = grow < Mv ? grow : Mv - 1;
                 res[buf][it] = *reinterpret_cast<const float4*>(
-                    g.add + (size_t)(grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
+                    g.add + (size_t)(PURE ? grow : grow / g.add_div) * g.ld_add + cbase + j * 32 + (lane & 7) * 4);
             }
         };
         // per-column epilogue vectors (bias; LayerNorm fold: column sums) are requested there too: loaded in the
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[i][j][r] + bias_l[j];
-                        if (g.act == BG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (k_relu) v = fmaxf(v, 0.f);
                         pf[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + (lane & 31)] = v;
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -772,11 +772,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                             v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
                         }
                         if (grow < Mv) {
-                            if (g.add2) {
+                            if (k_add2) {
                                 const float4 a4 = *reinterpret_cast<const float4*>(g.add2 + (size_t)(grow / g.add2_div) * g.ld_add2 + gcol);
                                 v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
                             }
-                            if (g.out_dtype != BG_F32)
+                            if (!PURE && g.out_dtype != BG_F32)
                                 *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
                                     E::pack4(v.x, v.y, v.z, v.w);
                             else
@@ -803,17 +803,23 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 }
 
 
-// opt-in profiler accounting of `rows` output rows: 2 M N K flops; bytes = operands once + output once (+ addends)
+// opt-in profiler accounting of `rows` output rows: 2 M N K flops; bytes = what the launch has to move once -- operands, output,
+// addends, and for the residual-stream forms the split residual read (hi + lo), the lo plane and the row statistics
 static void gemm_cost(const GemmArgs& g, double rows, double& flops, double& bytes) {
     const double osz = g.out_dtype == BG_F32 ? 4.0 : 2.0;
     flops = 2.0 * rows * g.N * (double)g.K;
     bytes = 2.0 * rows * g.K + 2.0 * g.N * (double)g.K + osz * rows * g.N + (g.add ? 4.0 * (rows / g.add_div) * g.N : 0.0) +
             (g.add2 ? 4.0 * (rows / g.add2_div) * g.N : 0.0);
+    if (g.bias) bytes += 4.0 * g.N;
+    if (g.out_lo) bytes += 2.0 * rows * g.N;                      // lo plane
+    if (g.res_hi) bytes += 4.0 * rows * g.N;                      // split residual in: hi + lo
+    if (g.stats_out) bytes += 8.0 * rows * (g.N_pad / 64);        // (sum, sum of squares) per row and 64-column group
+    if (g.stats_in) bytes += 8.0 * rows * (g.K / G_BK) + 4.0 * g.N;   // LayerNorm fold: the row partials + column sums
 }
 
 template <bool F16>
 static int launch16(const GemmArgs& g, hipStream_t s) {
-    const double rows_all = g.rows_hint > 0 ? g.rows_hint : g.M;  // (profiler accounting only)
+    const double rows_all = g.rows_hint > 0 ? g.rows_hint : g.M;  // (profiler accounting)
     double rows_tail = rows_all;
     const int m128 = (g.M + 127) / 128, m256 = (g.M + 255) / 256, n128 = g.N_pad / 128;
     if (g.N_pad % 128 != 0) {                                     // narrow outputs (fc_out.3: 6/18/48 -> padded 64; conv_out 3)
@@ -833,6 +839,14 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in || variant != 0)) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;
+    }
+    // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes every row count
+    // (bg_tune key 12 = 1: the 256 + 128 hybrid below instead, kept for the bit-equality test and A/B timing)
+    if (variant == 0 && g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g)) {
+        double fl, by;
+        gemm_cost(g, rows_all, fl, by);
+        ProfScope prof(PK_GEMM_SPLIT, fl, by, s);
+        return launch_split_pipe<F16>(g, s);
     }
     // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs, on the row panels that fill complete
     // rounds of 256 tiles; the 128 x 128 kernel below runs the remaining rows (bg_common.h: p256_rows).  With a device-side row
@@ -906,6 +920,9 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
             if (g.out_lo) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
             else if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
             else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
+        } else if (g.cv_C > 0 && g.act == BG_ACT_NONE && !g.add2 && g.add_div == 1 && g_tune[14] != 1) {
+            // implicit-GEMM convolution as the VAE passes issue it: fp32 output (+ fp32 residual of the same shape), options folded away
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
             hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
         } else if (g.out_lo && g.res_hi && g.stats_out && !g.add && !g.add2 && !g.row_map && g.act == BG_ACT_NONE && g_tune[14] != 1) {

@@ -57,7 +57,7 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-template <bool F16, int MODE, bool STATS = false>
+template <bool F16, int MODE, bool STATS = false, int ACT = -1>   // ACT: the activation as a compile-time constant (-1: g.act at run time)
 __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     constexpr bool FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16 || MODE == P_SPLIT, "16-bit output epilogues only");
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     const unsigned grp_lds = lds0 + (unsigned)(P256_RING + wm * 4 * P256_PATCH);
     const unsigned char* grp = lds + P256_RING + wm * 4 * P256_PATCH;
     const bool has_bias = g.bias != nullptr;
+    const bool relu = ACT < 0 ? g.act == BG_ACT_RELU : ACT == BG_ACT_RELU;
 
     // ---- LDS-DMA: wave w moves pieces w and w + 8 (8 rows x 128 B each) of every 128-row half-tile ----
     // Source = wave-uniform base (SGPR pair: tile origin + k offset + half offset) + 32-bit per-lane byte offset; the 16-byte chunk
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) {
                     const float x = acc[i][j][4 * q + e];
                     v[e] = FOLD ? ln_fold_apply(x, cf.x, cf.y, c4[e], b4[e]) : x + b4[e];
-                    if (g.act == BG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                    if (relu) v[e] = fmaxf(v[e], 0.f);
                 }
                 union { V4 v; uint2 u; } pk;
                 pk.v = E::pack4(v[0], v[1], v[2], v[3]);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                         const float4 p1 = *reinterpret_cast<const float4*>(patch + prow * 256 + (((2 * k8 + 1) ^ prow) << 4));
                         float v[8] = {p0.x + bias0.x, p0.y + bias0.y, p0.z + bias0.z, p0.w + bias0.w,
                                       p1.x + bias1.x, p1.y + bias1.y, p1.z + bias1.z, p1.w + bias1.w};
-                        if (g.act == BG_ACT_RELU) {
+                        if (relu) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
@@ -517,9 +518,16 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
     const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr, g.hybrid == 2) : g.M + 255) / 256) * (g.N_pad / 256);
     if (tiles == 0) return 0;
     const int grid = tiles < 256 ? tiles : 256;
+    // (bg_tune key 13 = 1: the instantiations that test g.act at run time, for the A/B)
+    const bool ct = g_tune[13] != 1, none = ct && g.act == BG_ACT_NONE, relu = ct && g.act == BG_ACT_RELU;
+    // (the split epilogue keeps the run-time check: with the constant its register allocation moves and three dwords spill)
     if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(512), 0, s, g);
     else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(512), 0, s, g);
+    else if (g.stats_in && none) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
+    else if (g.stats_in && relu) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false, BG_ACT_RELU>), dim3(grid), dim3(512), 0, s, g);
     else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16>), dim3(grid), dim3(512), 0, s, g);
+    else if (none) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
+    else if (relu) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false, BG_ACT_RELU>), dim3(grid), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16>), dim3(grid), dim3(512), 0, s, g);
     return launch_status("gemm16_p256");
 }

@@ -234,17 +234,34 @@ class _HipDenoiser(nn.Module):
         return class_label.reshape(-1).to(device=device, dtype=torch.int64).contiguous()
 
     def _row_hints(self, mask, S, E):
+        """(valid tokens, sum over samples of valid^2) of this mask -- the host-side ESTIMATE bg_denoiser_fwd takes (GEMM kernel
+        choice + profiler accounting; the kernels count the rows themselves).  Never a host synchronisation: a mask seen for the
+        first time is counted asynchronously (a few tiny kernels + a copy into pinned memory behind an event) and this call passes
+        0 = unknown; calls with the same mask tensor use the count once the event has fired.  A caller that builds a fresh mask
+        tensor every step (sample.py:197, 216: `mask.repeat(2, ...)`) therefore always runs with the estimate 0 -- correct, and
+        bit-identical to the run with the estimate."""
         if self.profile_hints:
             return self.profile_hints
-        if torch.cuda.is_current_stream_capturing():       # (a count needs a host synchronisation)
+        if torch.cuda.is_current_stream_capturing():
             return 0.0, 0.0
         key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
-        if self._hint_cache.get("key") != key:
+        hc = self._hint_cache
+        if hc.get("key") != key:
             valid = (~mask.reshape(mask.shape[0], -1).bool()).sum(1).double()
             if self.NET == BG_EDGEPOS:                     # the mask marks faces, every valid face carries E edge tokens
                 valid = valid * E
-            self._hint_cache = {"key": key, "hints": (float(valid.sum()), float((valid * valid).sum())), "keep": mask}
-        return self._hint_cache["hints"]
+            host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+            host.copy_(torch.stack([valid.sum(), (valid * valid).sum()]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            # (the entry keeps the mask alive: its storage cannot be recycled for another mask while it is the key)
+            self._hint_cache = {"key": key, "host": host, "event": ev, "hints": None, "keep": mask}
+            return 0.0, 0.0
+        if hc["hints"] is None:
+            if not hc["event"].query():
+                return 0.0, 0.0
+            hc["hints"] = (float(hc["host"][0]), float(hc["host"][1]))
+        return hc["hints"]
 
     def _run(self, x, timesteps, surf_pos, surf_z, edge_pos, mask, class_label, B, S, E, out_shape):
         if not x.is_cuda:
@@ -268,7 +285,8 @@ class _HipDenoiser(nn.Module):
         inp.cond_cache, inp.cond_cache_valid = None, 0
         inp.varlen = int(bool(self.varlen) and mk is not None and self.NET != BG_SURFPOS)
         # valid tokens / attention pairs of the batch: the host-side ESTIMATE the launcher uses to pick GEMM kernels (the device
-        # still counts the rows itself) and what the opt-in profiler books; counted once per mask tensor (identity + version)
+        # still counts the rows itself) and what the opt-in profiler books; counted once per mask tensor (identity + version),
+        # asynchronously -- 0 = unknown until the count has arrived
         inp.rows_hint, inp.pairs_hint = self._row_hints(mask, S, E) if inp.varlen else (0.0, 0.0)
         ns = self.n_split
         if ns == "auto":

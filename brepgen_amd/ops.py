@@ -62,17 +62,18 @@ def linear(a, w, bias=None, out_dtype=torch.float32, act=BG_ACT_NONE, add=None, 
 
 
 def linear_ex(a, w, bias=None, *, act=BG_ACT_NONE, out_dtype=None, add=None, add_div=1, add2=None, add2_div=1,
-              split_out=False, res=None, want_stats=False, stats_in=None, colsum=None, ln_eps=1e-5):
+              split_out=False, res=None, want_stats=False, stats_in=None, colsum=None, ln_eps=1e-5, inplace=False):
     """bg_gemm_ex_fwd.  Returns a dict: out (or hi), lo (split_out), stats (want_stats: [N/64, M, 2]).
 
-    res = (hi, lo) split residual rows added to the result; stats_in/colsum = LayerNorm fold on the A rows."""
+    res = (hi, lo) split residual rows added to the result; stats_in/colsum = LayerNorm fold on the A rows.
+    inplace (split_out + res): the result planes overwrite res, as the encoder layers run out-proj / FFN2."""
     _need_cuda(a, w, bias, add, add2, stats_in, colsum)
     assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.shape[1] == w.shape[1]
     a, w = a.contiguous(), w.contiguous()
     M, K = a.shape
     N = w.shape[0]
     odt = a.dtype if (split_out or out_dtype is None) else out_dtype
-    out = torch.empty(M, N, device=a.device, dtype=odt)
+    out = res[0] if inplace else torch.empty(M, N, device=a.device, dtype=odt)
     d = _lib.GemmDesc()
     d.a, d.lda, d.w, d.bias, d.out, d.ldc = ptr(a), K, ptr(w), ptr(bias), ptr(out), N
     d.M, d.N, d.N_pad, d.K = M, N, N, K
@@ -81,7 +82,7 @@ def linear_ex(a, w, bias=None, *, act=BG_ACT_NONE, out_dtype=None, add=None, add
     d.add2, d.ld_add2, d.add2_div = ptr(add2), (add2.shape[-1] if add2 is not None else 0), add2_div
     r = {"out": out}
     if split_out:
-        r["lo"] = torch.empty_like(out)
+        r["lo"] = res[1] if inplace else torch.empty_like(out)
         d.out_lo = ptr(r["lo"])
     if res is not None:
         d.res_hi, d.res_lo, d.ld_res = ptr(res[0]), ptr(res[1]), res[0].shape[-1]

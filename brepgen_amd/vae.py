@@ -258,6 +258,13 @@ class _HipVAE(nn.Module):
         self._packs, self._programs = {}, {}
         return super().load_state_dict(*a, **k)
 
+    def __setattr__(self, name, value):
+        # switches of earlier versions: an nn.Module would accept the assignment silently and nothing would change
+        if name in ("executor", "implicit_gemm"):
+            raise AttributeError(f"{type(self).__name__}.{name} no longer exists: every pass is one bg_vae_run program; the "
+                                 "step-by-step driver of the same kernels is tests/vae_stepwise.py")
+        super().__setattr__(name, value)
+
     def release_workspace(self):
         """Drop the cached bg_vae_run workspaces (up to WS_BUDGET bytes per (device, stream) this module has decoded on)."""
         self._ws = {}

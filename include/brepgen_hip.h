@@ -211,15 +211,20 @@ typedef struct {
      * of a valid query: network.py:1196, 1283, 1390); the reference computes -- and discards, sample.py:284, 307-314 --
      * values at padded positions.  The row count stays on the device: no host synchronisation. */
     int varlen;
-    /* expected number of valid tokens / sum over samples of valid^2, ONLY for the opt-in profiler's FLOP accounting
-     * (bg_profile_*); 0 = unknown (the profiler then books the padded sizes) */
+    /* Host-side ESTIMATE of the number of valid tokens / of the sum over samples of valid^2 (variable-length execution; 0 =
+     * unknown).  The row count that the kernels use is always the one counted on the device; the estimate only (a) lets the GEMM
+     * launcher choose between "256 x 256 + 128 x 128 kernels, split rule evaluated on the device" and "128 x 128 kernel alone"
+     * -- either choice is correct for ANY actual count, and the results are bit-identical -- and (b) is what the opt-in profiler
+     * (bg_profile_*) books as executed FLOPs / bytes.  With 0 the launcher plans for the bound B * S * E and the profiler books
+     * the padded sizes. */
     double rows_hint, pairs_hint;
     /* Software pipelining over independent sub-batches: n_split in 2..4 cuts the batch into that many contiguous
      * groups of samples and runs their forwards concurrently -- the first on `stream`, the others on helper streams
      * forked from it and joined back into it by events before the call returns (HIP-graph capturable).  Every op of the
      * path is per-sample and every kernel bit-stable across batch sizes, so the result is identical; what it buys is
      * occupancy: the tile-round tails and the memory-bound epilogues of one group hide under the K loops of another.
-     * 0 / 1 = off.  The helper streams and events are created lazily, once per process. */
+     * 0 / 1 = off; negative values are rejected.  The helper streams and events are created lazily, once per DEVICE (a process
+     * that drives several devices gets one set each), and used under a mutex (enqueue only). */
     int n_split;
     int _pad2;
 } bg_denoiser_inputs;

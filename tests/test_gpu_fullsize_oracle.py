@@ -38,6 +38,9 @@ CONFIGS = {
     "cfg3_deepcad_edgepos": ("EdgePosNet", 256, 60, 30, BF16, False, 8),
     "cfg4_abc_edgepos": ("EdgePosNet", 512, 100, 40, BF16, False, 8),
     "cfg5_furniture_cfg_fp16": ("EdgeZNet", 512, 60, 40, F16, True, 8),
+    # (round 4: the two nets of the rank-local ABC / furniture loops that had no full-size case)
+    "cfg4_abc_edgez": ("EdgeZNet", 512, 100, 40, BF16, False, 8),
+    "cfg5_furniture_cfg_edgepos_fp16": ("EdgePosNet", 512, 60, 40, F16, True, 8),
 }
 PER_SAMPLE = {"SurfPosNet": {0}, "SurfZNet": {0, 2, 3}, "EdgePosNet": {0, 2, 3, 4}, "EdgeZNet": {0, 2, 3, 4, 5}}
 

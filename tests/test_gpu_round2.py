@@ -157,15 +157,17 @@ def _rank_main(rank, world, port, Bs, S, E, noise_mode, q):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,noise_mode", [(2, "device"), pytest.param(2, "reference", marks=pytest.mark.slow),
+@pytest.mark.parametrize("world,noise_mode", [(3, "device"), pytest.param(2, "device", marks=pytest.mark.slow),
+                                              pytest.param(2, "reference", marks=pytest.mark.slow),
                                               pytest.param(4, "device", marks=pytest.mark.slow)])
 def test_cascade_sharded_over_processes_is_bit_identical(pc, world, noise_mode):
-    """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with UNEVEN splits --
-    B = 3 samples: world 2 -> shards of 2 and 1, world 4 -> one rank owns nothing; B = 1: only rank 0 owns a sample, the others
-    skip the compute and still join the collective -- equals the single-process cascade bit for bit: per-sample kernels, noise
-    keyed on the global sample index, one padded all-gather.  (Both batch sizes run in the same processes.)"""
+    """CascadeSampler(dist=...) over `world` processes (gloo rendezvous, all ranks on cuda:0) with UNEVEN splits and ranks that own
+    nothing -- world 3 (the case every -m gpu run executes): B = 4 -> shards of 2, 1 and 1; B = 1 -> only rank 0 owns a sample, the
+    other two skip the compute and still join the collective.  (world 2 / 4 with B = 3: shards 2 + 1 and 1 + 1 + 1 + 0, env-gated
+    duplicates.)  Equals the single-process cascade bit for bit: per-sample kernels, noise keyed on the global sample index, one
+    padded all-gather.  (Both batch sizes run in the same processes.)"""
     import torch.multiprocessing as mp
-    Bs, S, E = (3, 1), 4, 3
+    Bs, S, E = ((4, 1) if world == 3 else (3, 1)), 4, 3
     ref = _build_sampler(None, False, noise_mode)
     want = {B: {k: v.cpu() for k, v in ref.sample(B, S, E, generator=torch.Generator().manual_seed(31 + B), **SCHED).items()} for B in Bs}
     ctx = mp.get_context("spawn")

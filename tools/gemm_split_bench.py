@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Residual-stream GEMMs (out-proj K = 768, FFN2 K = 1024; split residual in place + row statistics): the software-pipelined
+kernel (csrc/gemm_split.hip, bg_tune key 12 = 0) against what ran them before -- the 256 + 128 hybrid (12 = 1) and the 128 x 128
+kernel alone (12 = 1, 10 = 2).  Bit-equality first, then interleaved timings (medians of R rounds of 20 launches), with the
+algorithmic bytes per launch (A + W + residual in (hi, lo) + (hi, lo) out + statistics) as GB/s next to the TFLOP/s.
+
+    python tools/gemm_split_bench.py [R] [M ...]"""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from brepgen_amd import _lib, ops
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+MS = [int(v) for v in sys.argv[2:]] or [8640, 15360, 17280, 30720, 61440, 138752]
+lib = _lib.load()
+dev = "cuda"
+g = torch.Generator().manual_seed(0)
+rn = lambda *s: torch.randn(*s, generator=g)
+VARS = [("128", {12: 1, 10: 2}), ("hybrid", {12: 1, 10: 0}), ("pipe", {12: 0, 10: 0})]
+
+
+def setv(kv):
+    for k, v in kv.items():
+        lib.bg_tune_set(k, v)
+
+
+def build(M, dt):
+    x = rn(M, 768) * 2
+    hi = x.to(dt).to(dev)
+    lo = (x - x.to(dt).float()).to(dt).to(dev)
+    cases = {}
+    for name, K in (("outproj", 768), ("ffn2", 1024)):
+        a = (rn(M, K) * 0.5).to(dt).to(dev)
+        w, b = (rn(768, K) * 0.04).to(dt).to(dev), rn(768).to(dev)
+        h, l = hi.clone(), lo.clone()                             # the in-place planes of the timed launches
+        cases[name] = (a, w, b, h, l, K)
+    return hi, lo, cases
+
+
+def timed(fn, n=20):
+    fn(); fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+bad = 0
+for dt in (torch.bfloat16, torch.float16):
+    for M in (1409, 4999, 17294, 30720 + 78):
+        hi, lo, cases = build(M, dt)
+        for name, (a, w, b, _, _, K) in cases.items():
+            outs = {}
+            for vn, kv in VARS:
+                setv(kv)
+                res = []
+                for rep in range(3):
+                    h, l = hi.clone(), lo.clone()
+                    r = ops.linear_ex(a, w, b, split_out=True, res=(h, l), want_stats=True, inplace=True)
+                    torch.cuda.synchronize()
+                    res.append(torch.cat([r["out"].float().flatten(), r["lo"].float().flatten(), r["stats"].flatten()]))
+                outs[vn] = res
+            ok = all(torch.equal(outs["128"][0], t) for v in outs.values() for t in v)
+            bad += not ok
+            if not ok or M == 4999:
+                nd = {vn: [int((outs["128"][0] != t).sum()) for t in v] for vn, v in outs.items()}
+                print(f"bit-equal {str(dt)[6:]:9s} M={M:6d} {name:8s} {ok} {nd if not ok else ''}")
+print("BIT-EQUALITY", "OK" if bad == 0 else f"FAILED ({bad} cases)", flush=True)
+
+dt = torch.bfloat16
+for M in MS:
+    hi, lo, cases = build(M, dt)
+    res = {(k, v[0]): [] for k in cases for v in VARS}
+    for r in range(R):
+        for vn, kv in VARS:
+            setv(kv)
+            for k, (a, w, b, h, l, K) in cases.items():
+                fn = lambda a=a, w=w, b=b, h=h, l=l: ops.linear_ex(a, w, b, split_out=True, res=(h, l), want_stats=True, inplace=True)
+                res[(k, vn)].append(timed(fn))
+    print(f"M = {M}")
+    for k, (a, w, b, h, l, K) in cases.items():
+        by = 2.0 * M * K + 2.0 * 768 * K + 8.0 * M * 768 + 8.0 * M * 12 + 4 * 768
+        line = f"  {k:8s} ({by / 1e6:6.1f} MB)"
+        for vn, _ in VARS:
+            us = statistics.median(res[(k, vn)])
+            line += f" | {vn} {us:6.1f} us {2.0 * M * 768 * K / us / 1e6:4.0f} TF {by / us / 1e3:5.0f} GB/s"
+        print(line, flush=True)
+setv({12: 0, 10: 0})
