@@ -20,7 +20,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib
 from ._lib import BG_BF16, BG_F16, BG_F32, check, ptr, stream
 
 _CODE = {torch.bfloat16: BG_BF16, torch.float16: BG_F16, torch.float32: BG_F32}

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import parity_cases as pc  # noqa: E402
-from brepgen_amd import ops  # noqa: E402
+import hip_ops as ops  # noqa: E402
 
 F32, BF16 = torch.float32, torch.bfloat16
 QUICK = "--quick" in sys.argv

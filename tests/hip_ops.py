@@ -1,12 +1,12 @@
-"""Thin tensor-level wrappers over the C ABI (one function per exported kernel entry point).
-
-Used by the drop-in modules and by the parity tests; every function enqueues on the current torch HIP stream
-and returns torch tensors that own the output memory.  No torch math here -- only allocation and pointers.
+"""Test / tool infrastructure: thin tensor-level wrappers over the C ABI (one function per exported kernel entry point), so that
+the parity tests and the benchmarking tools can call single kernels.  The product modules (brepgen_amd/*.py) bind the entry points
+they use themselves; nothing in the package imports this file.  Every function enqueues on the current torch HIP stream and
+returns torch tensors that own the output memory.  No torch math here -- only allocation and pointers.
 """
 import torch
 
-from . import _lib
-from ._lib import BG_ACT_NONE, BG_ACT_RELU, BG_BF16, BG_F16, BG_F32, check, ptr, stream  # noqa: F401
+from brepgen_amd import _lib
+from brepgen_amd._lib import BG_ACT_NONE, BG_ACT_RELU, BG_BF16, BG_F16, BG_F32, check, ptr, stream  # noqa: F401
 
 _DT = {torch.float32: BG_F32, torch.bfloat16: BG_BF16, torch.float16: BG_F16}
 
@@ -112,7 +112,7 @@ def layernorm_split(hi, lo, gamma, beta, eps=1e-5):
 def embed_ln_silu(x, k, w0, b0, gamma, beta, out_dtype=torch.float32, eps=1e-5):
     """SiLU(LayerNorm(x[:, :k] @ w0.T + b0)) through the fused kernel; x fp32 [rows, lda >= k] (a column-offset view
     with unit column stride is fine), w0 fp32 [768, k]."""
-    from .network import mfma_operand_order
+    from brepgen_amd.network import mfma_operand_order
     _need_cuda(x, w0, b0, gamma, beta)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and w0.shape == (768, k)
     rows, lda = x.shape[0], x.stride(0)

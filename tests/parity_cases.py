@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 import brepgen_amd as bga
-from brepgen_amd import ops
+import hip_ops as ops
 from oracle import denoisers as orc
 from oracle.schedulers import OracleDDPM, OraclePNDM
 

@@ -53,7 +53,7 @@ def test_attention_running_max_rescale_is_exact(pc, N, spike_at):
     """One key far into the sequence gets a logit ~40 above everything before it for half of the queries: the running
     max must jump at that tile and everything accumulated so far must be rescaled by exp(-40) -- a rescale slip of a
     few percent shows up as an O(few %) relative error; asserted at the bf16 rounding of P and O (2^-8 relative)."""
-    from brepgen_amd import ops
+    import hip_ops as ops
     g = torch.Generator().manual_seed(3)
     B = 2
     qkv = torch.randn(B * N, 2304, generator=g)
@@ -491,7 +491,8 @@ def test_gemm_256_tile_variant_is_bit_identical(pc):
     """bg_tune key 0 = 6 routes the 16-bit GEMMs with N % 256 == 0 to gemm16_kernel<256, 256, 2 x 4 waves> (128 x 64 per wave,
     the epilogue staged 64 rows at a time).  Same k order per output element -> the same bits as the shipped persistent
     kernel in every epilogue mode (LayerNorm fold, split residual + row statistics, fp32 + addend), ragged row count."""
-    from brepgen_amd import _lib, ops
+    from brepgen_amd import _lib
+    import hip_ops as ops
     lib = _lib.load()
     g = torch.Generator().manual_seed(3)
     M = 2 * 256 + 77

@@ -47,7 +47,7 @@ def tune():
 
 # ---- the 256 x 256 persistent GEMM -------------------------------------------------------------------------------------
 def _gemm_cases(M, dt, seed=0):
-    from brepgen_amd import ops
+    import hip_ops as ops
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     x = rn(M, 768) * 2

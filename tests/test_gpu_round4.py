@@ -63,7 +63,7 @@ def test_split_pipe_gemm_is_bit_identical(pc, tune, dt, K, M):
     256 + 128 hybrid (key 12 = 1) and the 128 x 128 kernel alone (key 12 = 1, key 10 = 2): hi, lo and the statistics, out of place
     and in place.  M covers one tile per workgroup (1409: 12 panels), many tiles per workgroup, ragged last panels.  Repeated: a race
     between the K loop and the epilogue it carries would not necessarily show the first time."""
-    from brepgen_amd import ops
+    import hip_ops as ops
     a, w, b, hi, lo = _split_case(M, K, dt)
 
     def run(inplace):

@@ -12,7 +12,8 @@ import math
 
 import torch
 
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+import hip_ops as ops
 from brepgen_amd._lib import BG_F32, check, ptr, stream
 from brepgen_amd.vae import ACT_GELU, ACT_NONE, ACT_SILU, _CODE, _pow2
 

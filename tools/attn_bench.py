@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 
 lib = _lib.load()
 g = torch.Generator().manual_seed(0)

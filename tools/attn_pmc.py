@@ -4,7 +4,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from brepgen_amd import ops
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 g = torch.Generator().manual_seed(0)
 B, N = 256, 1800
 qkv = (torch.randn(B * N, 2304, generator=g) * 0.7).to(torch.bfloat16).cuda()

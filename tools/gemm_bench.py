@@ -8,7 +8,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
-from brepgen_amd import _lib, ops  # noqa: E402
+from brepgen_amd import _lib
+import hip_ops as ops  # noqa: E402
 
 BF16, F32 = torch.bfloat16, torch.float32
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3,4").split(",")]

@@ -4,7 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 BF16, F32 = torch.bfloat16, torch.float32
 lib = _lib.load()
 M = 30720

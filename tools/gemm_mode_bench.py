@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 30720

@@ -10,7 +10,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 
 MS = [int(v) for v in sys.argv[1:]] or [8640, 17280, 30720, 61440, 138752]
 lib = _lib.load()

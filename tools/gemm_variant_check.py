@@ -8,7 +8,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from brepgen_amd import _lib, ops
+from brepgen_amd import _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hip_ops as ops
 
 VAR = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 MS = [int(v) for v in sys.argv[2:]] or [17280, 138752]
