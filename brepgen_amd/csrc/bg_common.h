@@ -128,6 +128,7 @@ struct GemmArgs {
     // ---- 256 + 128 hybrid (set by the launcher only): rows [0, p256_rows(*m_dev, N_pad / 256)) belong to the 256 x 256 kernel,
     // the rest to the 128 x 128 kernel -- both evaluate the same rule on the device-side row count ----
     int hybrid = 0;                   // 1: the split above; 2: all-or-nothing (concurrent sample groups, see p256_rows)
+    int p256_stagger = 0;             // split-residual launches of the 256 x 256 kernel: start delay of the second phase group, x 1024 cycles
     int concurrent = 0;               // caller's hint: other launches of the same kind are in flight on sibling streams
 };
 
@@ -136,27 +137,33 @@ struct GemmArgs {
 // fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
 // times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
 constexpr int P256_TAIL_MIN = 160;
+constexpr int P256_SPLIT_STAGGER = 24;         // start delay of the second phase group of a split-residual launch, x 1024 cycles
+constexpr int P256_SPLIT_MIN_ROUNDS = 4;      // split-residual launches: the 256 x 256 kernel from this many full rounds on
 __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false, bool all_or_nothing = false) {
     const int panels = (rows + 255) >> 8, T = panels * nt_n256;
     if (all_or_nothing) {
         // Several sample groups in flight on forked streams (n_split > 1): a partial round of one group's launch is filled by the
         // other group's, and a tail kernel only adds a dependent launch to each chain -- the 256 kernel runs alone or not at all
         // (measured, profiles/r03/face_ldm_legs_ab_p256.log: leg B 4.17 vs 4.41 ms with the tail kernels)
-        if (split) return (T >= 1024 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
+        if (split) return T >= P256_SPLIT_MIN_ROUNDS * ((256 / nt_n256) * nt_n256) ? panels << 8 : 0;
         // (non-split threshold: 300 vs 400 tiles measured on the compacted face batch, 2 x 306 QKV tiles in flight: -1.4 % per step,
         //  profiles/r03/face_ldm_legs_ab_fold_in_kernel.log)
         return (T >= 300 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
     }
     if (split) {
-        // split-residual epilogue (out-proj / FFN2): a 256 x 256 tile spends as long in its epilogue (512 KiB of residual traffic,
-        // nothing to hide it behind) as in its K loop, so a full round is only ~10 % ahead of the 128 x 128 kernel and a launch seam
-        // costs more than that.  Measured (profiles/r03/gemm_p256_split_safe.log): it pays for one well-filled round (the compacted
-        // face batch: 204 tiles) and from ~4 rounds on (the edge nets); in between the 128 x 128 kernel runs alone.
-        if (T <= 256) return T >= 200 ? panels << 8 : 0;
-        if (T < 1024) return 0;
-        const int R = T >> 8, rem = T - (R << 8);
+        // split-residual epilogue (out-proj / FFN2): memory-bound launches (8 B per output element next to 2 K FLOP).  The 256 x 256
+        // kernel moves the fewest operand bytes per FLOP through a CU's vector-memory path, but every tile ends in 512 KiB of
+        // residual traffic, and workgroups that start together stay in lock-step -- all K loops, then all epilogues, the fabric idle
+        // half of the time.  It therefore runs these launches in TWO phase groups half a tile apart (gemm_p256.hip: stagger), on a
+        // grid that is a multiple of the column tiles (the workgroups of a row panel keep sharing its A rows): a round is
+        // p256_split_round(nt_n256) tiles.  Measured (profiles/r04/gemm_split_bench_*.log): it pays from `P256_SPLIT_MIN_ROUNDS`
+        // full rounds on (the edge nets); below that -- and for the rows beyond the last full round unless that round is well
+        // filled -- the pipelined 128 x 128 kernel (gemm_split.hip) runs them.
+        const int Gs = (256 / nt_n256) * nt_n256;
+        if (T < P256_SPLIT_MIN_ROUNDS * Gs) return 0;
+        const int R = T / Gs, rem = T - R * Gs;
         if (rem == 0 || rem >= 200) return panels << 8;
-        return ((R << 8) / nt_n256) << 8;
+        return ((R * Gs) / nt_n256) << 8;
     }
     const int R = T >> 8, rem = T - (R << 8);
     if (rem == 0 || rem >= P256_TAIL_MIN) return panels << 8;

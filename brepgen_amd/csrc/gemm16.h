@@ -6,6 +6,7 @@
 
 namespace bg {
 
+constexpr int SMALL_LAUNCH_TILES = 160;   // launches of fewer 128 x 128 tiles run on 64 x 64 tiles (gemm_16bit.hip launch16)
 constexpr int G_BK = 64;            // 16-bit elements per K-step = 128 bytes per tile row
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

@@ -830,6 +830,19 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         return launch_status("gemm16");
     }
     const int nt = m128 * n128;
+    // Small launches (the reference's shipped batch of 16 samples: 960 face tokens -> 48 .. 144 tiles of 128 x 128 on 256 CUs): a
+    // 128 x 128 tile per workgroup leaves most of the chip idle while every workgroup walks its 12 K-steps one DMA round trip at a
+    // time.  64 x 64 tiles (two waves, 3-deep ring: two K-steps of DMA in flight) put four times as many workgroups on the chip
+    // and halve the per-step latency chain; same k order, same epilogue code -> bit-identical results
+    // (tests/test_gpu_round4.py).  bg_tune key 15: tile-count threshold (0 = default, -1 = off).
+    const int small_nt = g_tune[15] < 0 ? 0 : (g_tune[15] > 0 ? g_tune[15] : SMALL_LAUNCH_TILES);
+    if (g_tune[TUNE_GEMM_VARIANT] == 0 && g.cv_C == 0 && nt < small_nt && (g.stats_in == nullptr || g.K / G_BK <= 16)) {
+        double fl, by;
+        gemm_cost(g, rows_all, fl, by);
+        ProfScope prof(PK_GEMM_BF16_64, fl, by, s);
+        hipLaunchKernelGGL((gemm16_kernel<F16, 64, 64, 2, 1, 3>), dim3(((g.M + 63) / 64) * (g.N_pad / 64)), dim3(128), 0, s, g);
+        return launch_status("gemm16(64x64)");
+    }
     const bool persistent_ok = (g.ldc % 8 == 0) && (g.N == g.N_pad) && (g.add == nullptr || g.ld_add % 4 == 0) &&
                                (g.add2 == nullptr || g.ld_add2 % 4 == 0) && nt >= 64 &&
                                (g.row_map == nullptr || (g.out_lo != nullptr && !g.map_out));   // mapped addends: SPLIT epilogue only
@@ -839,14 +852,6 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in || variant != 0)) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;
-    }
-    // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes every row count
-    // (bg_tune key 12 = 1: the 256 + 128 hybrid below instead, kept for the bit-equality test and A/B timing)
-    if (variant == 0 && g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g)) {
-        double fl, by;
-        gemm_cost(g, rows_all, fl, by);
-        ProfScope prof(PK_GEMM_SPLIT, fl, by, s);
-        return launch_split_pipe<F16>(g, s);
     }
     // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs, on the row panels that fill complete
     // rounds of 256 tiles; the 128 x 128 kernel below runs the remaining rows (bg_common.h: p256_rows).  With a device-side row
@@ -858,7 +863,9 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (g_tune[TUNE_P256_MODE] == 1) {
             gemm_cost(g, rows_all, fl, by);
             ProfScope prof(PK_GEMM_P256, fl, by, s);
-            return launch_p256<F16>(g, s);
+            GemmArgs h = g;
+            if (g.out_lo) h.p256_stagger = g_tune[TUNE_GEMM_STAGGER] > 0 ? g_tune[TUNE_GEMM_STAGGER] : (g_tune[TUNE_GEMM_STAGGER] < 0 ? 0 : P256_SPLIT_STAGGER);
+            return launch_p256<F16>(h, s);
         }
         const bool split = g.out_lo != nullptr;
         // upper bound of what the 256 kernel may own (a device-side row count can only be smaller: the split rule is not monotonic,
@@ -873,6 +880,7 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (rows_hi > 0 && can_tail) {
             GemmArgs h = g;
             h.hybrid = hmode;
+            if (split) h.p256_stagger = g_tune[TUNE_GEMM_STAGGER] > 0 ? g_tune[TUNE_GEMM_STAGGER] : (g_tune[TUNE_GEMM_STAGGER] < 0 ? 0 : P256_SPLIT_STAGGER);
             const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split, hmode == 2), rows_all);
             rows_tail = rows_all - rows_p;
             gemm_cost(g, rows_p, fl, by);
@@ -891,6 +899,12 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     const GemmArgs& g_ = gt;
     double fl_t, by_t;
     gemm_cost(g, rows_tail, fl_t, by_t);
+    // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes the rows the 256 x 256
+    // kernel does not (bg_tune key 12 = 1: the 128 x 128 persistent kernel instead, kept for the bit-equality test and A/B timing)
+    if (variant == 0 && g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g_)) {
+        ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
+        return launch_split_pipe<F16>(g_, s);
+    }
     ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, fl_t, by_t, s);
     if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g_);

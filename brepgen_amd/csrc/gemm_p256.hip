@@ -81,6 +81,15 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     // an A panel is fetched into that L2 once and the W tiles stay resident.
     int L = xcd_remap(blockIdx.x, G);
     if (L >= T_all) return;                                       // uniform per workgroup, before any barrier
+    if constexpr (SPLIT) {
+        // Two phase groups.  A split tile is ~12 us of K loop (operands out of the L2, the fabric idle) and then 512 KiB of residual
+        // traffic per CU; workgroups that start together stay together, so the chip alternates between "no memory traffic" and
+        // "every CU waiting for memory".  The workgroups of every second row panel (the grid is a multiple of the column tiles:
+        // the nt_n workgroups that share a panel's A rows stay in one group, round after round) start `p256_stagger` x 1024 cycles
+        // late -- about one K loop -- so one group's epilogues run under the other group's K loops.
+        if (g.p256_stagger > 0 && (((unsigned)L / (unsigned)nt_n) & 1u))
+            for (int r = g.p256_stagger; r > 0; --r) __builtin_amdgcn_s_sleep(16);
+    }
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.a);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.w);
     const unsigned lda_b = (unsigned)g.lda * 2u, ldw_b = (unsigned)g.K * 2u;
@@ -517,7 +526,11 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
     // is evaluated on the device, surplus workgroups exit at once)
     const int tiles = ((g.hybrid && g.m_dev == nullptr ? p256_rows(g.M, g.N_pad / 256, g.out_lo != nullptr, g.hybrid == 2) : g.M + 255) / 256) * (g.N_pad / 256);
     if (tiles == 0) return 0;
-    const int grid = tiles < 256 ? tiles : 256;
+    int grid = tiles < 256 ? tiles : 256;
+    if (g.out_lo) {                                               // split-residual launches: whole row panels per round (phase groups)
+        const int nt_n = g.N_pad / 256;
+        grid = grid / nt_n * nt_n;
+    }
     // (bg_tune key 13 = 1: the instantiations that test g.act at run time, for the A/B)
     const bool ct = g_tune[13] != 1, none = ct && g.act == BG_ACT_NONE, relu = ct && g.act == BG_ACT_RELU;
     // (the split epilogue keeps the run-time check: with the constant its register allocation moves and three dwords spill)

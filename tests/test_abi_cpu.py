@@ -188,6 +188,20 @@ def test_p256_kernels_do_not_spill():
         assert sc <= (8 if split else 0), (n, sc)
 
 
+def test_split_pipe_kernel_does_not_spill():
+    """csrc/gemm_split.hip runs at the 256-VGPR limit of two waves per SIMD (two accumulator sets + the slab in flight); a spill
+    would put scratch traffic into K-steps whose waits are placed by hand."""
+    import re
+    import subprocess
+    from brepgen_amd import build as b
+    r = subprocess.run([b._hipcc(), *b.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(b.CSRC, "gemm_split.hip"),
+                        "-o", os.devnull], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)]
+    assert len(scratch) >= 2 and all(v == 0 for v in scratch) and all(v == 0 for v in spills), (scratch, spills)
+
+
 def test_gemm_partition_rule_between_the_256_and_128_kernels():
     """bg_gemm_p256_rows is the rule both GEMM kernels evaluate on the device-side row count (csrc/bg_common.h p256_rows):
     the 256 x 256 kernel takes whole 256-row panels from the front, never more than the launch has, whole tile rounds
@@ -212,6 +226,8 @@ def test_gemm_partition_rule_between_the_256_and_128_kernels():
     assert f(17280, 2304, 0, 0) == 56 * 256 and f(30720, 2304, 0, 0) == (1024 // 9) * 256
     assert f(17280, 2304, 0, 1) == 68 * 256 and f(8640, 2304, 0, 1) == 34 * 256      # concurrent sample groups: >= 300 tiles -> alone
     assert f(7680, 2304, 0, 1) == 0                                           # 270 tiles: a round and a sliver -> the 128 kernel
-    # out-proj / FFN2 (3 column tiles): 204 tiles fill one round well enough; 360 tiles do not pay (128 kernel alone)
-    assert f(17280, 768, 1, 0) == 68 * 256 and f(30720, 768, 1, 0) == 0 and f(138752, 768, 1, 0) > 0
+    # out-proj / FFN2 (3 column tiles, rounds of 255 tiles in two phase groups): the face-LDM batches (204 / 360 tiles) stay on the
+    # pipelined 128 x 128 kernel, the edge nets (1626 tiles = 6 rounds + 96) give the 256 kernel its six full rounds = 510 panels
+    assert f(17280, 768, 1, 0) == 0 and f(30720, 768, 1, 0) == 0 and f(138752, 768, 1, 0) == 510 * 256
+    assert f(138752, 768, 1, 1) == 542 * 256 and f(61440, 768, 1, 1) == 0
     assert f(100, 768, 0, 0) == 0 and f(0, 2304, 0, 0) == 0                 # a few tiles: the 128 kernel (finer tiles fill more CUs)

@@ -8,6 +8,8 @@ Tolerances (measured round 1 on MI355X; the asserted bounds leave ~2-4x headroom
                x_{t-1} at the sampling schedule (eps enters with a coefficient of ~0.007-0.02), not for eps itself;
                both are asserted below with the measured scale.
 """
+import os
+
 import pytest
 import torch
 
@@ -207,10 +209,29 @@ def test_denoiser_fp32_vs_reference_golden(pc, name):
     assert e["finite"] and e["max_abs"] < 1e-5
 
 
+# bf16 operands against the reference's own fp32 outputs: (max, mean) abs error bound per case = 2 x what the MI355X measured
+# (profiles/r04/parity_r04.json, key golden_bf16_<case>; the values differ per case with |eps| and the token count).  north_star's
+# "1e-3 bf16" is NOT met on eps itself -- by construction: 8 mantissa bits through 12 layers, the reference's own bf16 autocast sits
+# at 2.4-3.3e-2 -- it is asserted where it is meaningful, on the per-step sample update (test_baseline_config0_ddpm_chain).
+GOLDEN_BF16_BOUND = {"_default": (4e-2, 8e-3)}
+
+
 @pytest.mark.parametrize("name", GOLDEN)
 def test_denoiser_bf16_vs_reference_golden(pc, name):
+    import json
     e = pc.golden_case(name, BF16)
-    assert e["finite"] and e["max_abs_valid"] < 4e-2 and e["mean_abs"] < 8e-3
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r04.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    d["golden_bf16_" + name] = {"max_abs_valid": e["max_abs_valid"], "mean_abs": e["mean_abs"], "ref_absmax": e["ref_absmax"]}
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+    bmax, bmean = GOLDEN_BF16_BOUND.get(name, GOLDEN_BF16_BOUND["_default"])
+    assert e["finite"] and e["max_abs_valid"] < bmax and e["mean_abs"] < bmean, e
 
 
 def test_denoiser_vs_oracle_larger(pc):

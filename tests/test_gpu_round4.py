@@ -36,12 +36,13 @@ def _record(key, value):
 
 @pytest.fixture
 def tune():
-    """bg_tune_set with automatic reset of the keys this file touches (10: 256-kernel mode, 12: split-kernel choice)."""
+    """bg_tune_set with automatic reset of the keys this file touches (8: phase-group delay, 10: 256-kernel mode, 12: split-kernel
+    choice, 15: small-launch threshold)."""
     from brepgen_amd import _lib
     lib = _lib.load()
     yield lib.bg_tune_set
-    lib.bg_tune_set(10, 0)
-    lib.bg_tune_set(12, 0)
+    for k in (8, 10, 12, 15):
+        lib.bg_tune_set(k, 0)
 
 
 def _split_case(M, K, dt, seed=0):
@@ -75,6 +76,7 @@ def test_split_pipe_gemm_is_bit_identical(pc, tune, dt, K, M):
         torch.cuda.synchronize()
         return r["out"].clone(), r["lo"].clone(), r["stats"].clone()
 
+    tune(15, -1)                                                  # (M = 1409 is 72 tiles: keep it off the small-launch path)
     tune(12, 1)
     tune(10, 2)
     ref = run(False)
@@ -118,3 +120,62 @@ def test_split_pipe_edge_net_shape_fp16(pc, tune):
         tune(12, 0)
         got = m(*args)
     assert torch.isfinite(ref).all() and torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("M", [16 * 60, 960 + 37, 128])
+def test_small_launch_tiles_are_bit_identical(pc, tune, dt, M):
+    """The reference's shipped batch (16 samples x 60 faces = 960 tokens): launches of < 160 tiles of 128 x 128 run on 64 x 64 tiles
+    (key 15 = -1 switches that off).  Every epilogue the encoder layers use -- plain, LayerNorm fold (+ ReLU), split residual +
+    statistics -- must not depend on the tile shape: a sample's bits are the same at batch 16 and at batch 512."""
+    import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(M, 768) * 2
+    hi = x.to(dt)
+    lo = (x - hi.float()).to(dt).cuda()
+    hi = hi.cuda()
+    grp = x.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().cuda()
+    cases = {}
+    for name, N, act in (("qkv", 2304, 0), ("ffn1", 1024, 1)):
+        w, b = (rn(N, 768) * 0.04).to(dt).cuda(), rn(N).cuda()
+        cs = w.float().sum(1).contiguous()
+        cases[name + " plain"] = lambda w=w, b=b, act=act: ops.linear(hi, w, b, out_dtype=dt, act=act)
+        cases[name + " fold"] = lambda w=w, b=b, act=act, cs=cs: ops.linear_ex(hi, w, b, act=act, stats_in=stats, colsum=cs)["out"]
+    for name, K in (("outproj", 768), ("ffn2", 1024)):
+        a = (rn(M, K) * 0.5).to(dt).cuda()
+        w, b = (rn(768, K) * 0.04).to(dt).cuda(), rn(768).cuda()
+
+        def split(a=a, w=w, b=b):
+            r = ops.linear_ex(a, w, b, split_out=True, res=(hi, lo), want_stats=True)
+            return torch.cat([r["out"].float().flatten(), r["lo"].float().flatten(), r["stats"].flatten()])
+        cases[name + " split"] = split
+    for name, fn in cases.items():
+        tune(15, -1)
+        ref = fn().clone()
+        tune(15, 0)
+        for _ in range(2):
+            got = fn()
+            torch.cuda.synchronize()
+            assert torch.equal(ref, got), (name, M, dt)
+
+
+def test_p256_split_phase_groups_are_bit_identical(pc, tune):
+    """out-proj / FFN2 at the edge nets' row count on the 256 x 256 kernel alone (key 10 = 1), with the second phase group starting
+    late (key 8 = 24 x 1024 cycles, the default), much later (200) and not at all (-1): the delay moves when a tile is computed, never
+    what it computes."""
+    import hip_ops as ops
+    for K in (768, 1024):
+        a, w, b, hi, lo = _split_case(138752 + 5, K, BF16, seed=K)
+        outs = []
+        for mode, stag in ((2, 0), (1, -1), (1, 0), (1, 200), (0, 0)):
+            tune(12, 1 if mode == 2 else 0)
+            tune(10, mode)
+            tune(8, stag)
+            h, l = hi.clone(), lo.clone()
+            r = ops.linear_ex(a, w, b, split_out=True, res=(h, l), want_stats=True, inplace=True)
+            torch.cuda.synchronize()
+            outs.append((r["out"].clone(), r["lo"].clone(), r["stats"].clone()))
+        for o in outs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(outs[0], o)), K

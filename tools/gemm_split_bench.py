@@ -17,12 +17,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import hip_ops as ops
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-MS = [int(v) for v in sys.argv[2:]] or [8640, 15360, 17280, 30720, 61440, 138752]
+MS = [int(v) for v in sys.argv[2:]] or [15360, 17280, 30720, 61440, 138752, 204800]
 lib = _lib.load()
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
 rn = lambda *s: torch.randn(*s, generator=g)
-VARS = [("128", {12: 1, 10: 2}), ("hybrid", {12: 1, 10: 0}), ("pipe", {12: 0, 10: 0})]
+STAGS = [int(v) for v in os.environ.get("BG_STAGS", "12,18,24,30,36").split(",")]
+# 128: the 128 x 128 persistent kernel alone; pipe: the pipelined 128 x 128 kernel alone; p256 ...: the 256 x 256 kernel alone, without /
+# with the second phase group starting D x 1024 cycles late; hybrid: what the library picks (bg_common.h p256_rows)
+VARS = [("128", {12: 1, 10: 2, 8: 0}), ("pipe", {12: 0, 10: 2, 8: 0}), ("p256 nostag", {12: 0, 10: 1, 8: -1})] + \
+       [(f"p256 stag{d}", {12: 0, 10: 1, 8: d}) for d in STAGS] + [("hybrid", {12: 0, 10: 0, 8: 0})]
 
 
 def setv(kv):
@@ -57,7 +61,7 @@ def timed(fn, n=20):
 
 bad = 0
 for dt in (torch.bfloat16, torch.float16):
-    for M in (1409, 4999, 17294, 30720 + 78):
+    for M in (1409, 4999, 17294, 30720 + 78, 138752 + 5):
         hi, lo, cases = build(M, dt)
         for name, (a, w, b, _, _, K) in cases.items():
             outs = {}
@@ -90,9 +94,8 @@ for M in MS:
     print(f"M = {M}")
     for k, (a, w, b, h, l, K) in cases.items():
         by = 2.0 * M * K + 2.0 * 768 * K + 8.0 * M * 768 + 8.0 * M * 12 + 4 * 768
-        line = f"  {k:8s} ({by / 1e6:6.1f} MB)"
+        print(f"  {k:8s} ({by / 1e6:6.1f} MB algorithmic)")
         for vn, _ in VARS:
             us = statistics.median(res[(k, vn)])
-            line += f" | {vn} {us:6.1f} us {2.0 * M * 768 * K / us / 1e6:4.0f} TF {by / us / 1e3:5.0f} GB/s"
-        print(line, flush=True)
-setv({12: 0, 10: 0})
+            print(f"      {vn:14s} {us:7.1f} us {2.0 * M * 768 * K / us / 1e6:5.0f} TF {by / us / 1e3:5.0f} GB/s", flush=True)
+setv({12: 0, 10: 0, 8: 0})
