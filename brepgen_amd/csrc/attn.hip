@@ -253,7 +253,7 @@ constexpr int AL_MAX_N = 4096;       // longest sequence the long kernel stages 
 template <bool F16, bool MASKED>      // MASKED: a key-padding mask is given (dense execution); otherwise only keys >= N are dead
 __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
                                                              void* __restrict__ out_, int B, int N, int nqb,
-                                                             const int* __restrict__ offsets, int prio) {
+                                                             const int* __restrict__ offsets) {
     using E = AElem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -386,7 +386,6 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
 
         // ---- S^T = K Q^T for both 32-key sub-tiles ----
         f32x16 s[2];
-        if (prio) __builtin_amdgcn_s_setprio(1);                 // A/B knob (bg_tune key 7): matrix segments at priority 1
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -397,7 +396,6 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
                 s[sub] = E::mfma(kf, qf[ks], s[sub]);
             }
         }
-        if (prio) __builtin_amdgcn_s_setprio(0);
         // register r of sub-tile sub <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query (lane & 31)
         if (MASKED) {
             if (tflag[t]) {
@@ -562,7 +560,7 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             const dim3 grid(1, BG_N_HEAD / 2, B);
             if (f16) hipLaunchKernelGGL((attn16_kernel<2, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
             else hipLaunchKernelGGL((attn16_kernel<2, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
-        } else if (g_tune[6] == 1 || N > AL_MAX_N) {               // A/B baseline / very long sequences: the round-1 single-buffered kernel
+        } else if (N > AL_MAX_N) {                                  // sequences beyond the long kernel's mask staging: the single-buffered kernel
             const dim3 grid((N + 127) / 128, BG_N_HEAD, B);
             if (f16) hipLaunchKernelGGL((attn16_kernel<4, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
             else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
@@ -570,10 +568,10 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             const int nqb = (N + 127) / 128;
             const dim3 grid(nqb * BG_N_HEAD * B);
             const bool masked = key_pad != nullptr && offsets == nullptr;
-            if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
-            else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
-            else if (masked) hipLaunchKernelGGL((attn16_long_kernel<false, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
-            else hipLaunchKernelGGL((attn16_long_kernel<false, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, g_tune[7]);
+            if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            else if (masked) hipLaunchKernelGGL((attn16_long_kernel<false, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            else hipLaunchKernelGGL((attn16_long_kernel<false, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
         }
         return launch_status("attn16");
     }

@@ -34,7 +34,9 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 };
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
-enum TuneKey { TUNE_GEMM_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_COUNT = 16 };
+// (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
+//  15: small-launch threshold -- each backs a bit-equality test, see gemm_16bit.hip launch16)
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -137,30 +139,31 @@ struct GemmArgs {
 // fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
 // times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
 constexpr int P256_TAIL_MIN = 160;
-constexpr int P256_SPLIT_STAGGER = 24;         // start delay of the second phase group of a split-residual launch, x 1024 cycles
-constexpr int P256_SPLIT_MIN_ROUNDS = 4;      // split-residual launches: the 256 x 256 kernel from this many full rounds on
+constexpr int P256_SPLIT_STAGGER = 24;         // start delay of the second phase group of a split-residual launch, x 1024 cycles ...
+constexpr int P256_SPLIT_STAGGER_ROUNDS = 5;   // ... from this many rounds on (+1-3 % there, a loss below: profiles/r04/gemm_split_bench_sweep.log)
+constexpr int P256_SPLIT_MIN_HALF_ROUNDS = 5;  // split-residual launches: the 256 x 256 kernel from 2.5 rounds of tiles on
 __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false, bool all_or_nothing = false) {
     const int panels = (rows + 255) >> 8, T = panels * nt_n256;
     if (all_or_nothing) {
         // Several sample groups in flight on forked streams (n_split > 1): a partial round of one group's launch is filled by the
         // other group's, and a tail kernel only adds a dependent launch to each chain -- the 256 kernel runs alone or not at all
         // (measured, profiles/r03/face_ldm_legs_ab_p256.log: leg B 4.17 vs 4.41 ms with the tail kernels)
-        if (split) return T >= P256_SPLIT_MIN_ROUNDS * ((256 / nt_n256) * nt_n256) ? panels << 8 : 0;
+        if (split) return 2 * T >= P256_SPLIT_MIN_HALF_ROUNDS * ((256 / nt_n256) * nt_n256) ? panels << 8 : 0;
         // (non-split threshold: 300 vs 400 tiles measured on the compacted face batch, 2 x 306 QKV tiles in flight: -1.4 % per step,
         //  profiles/r03/face_ldm_legs_ab_fold_in_kernel.log)
         return (T >= 300 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
     }
     if (split) {
-        // split-residual epilogue (out-proj / FFN2): memory-bound launches (8 B per output element next to 2 K FLOP).  The 256 x 256
-        // kernel moves the fewest operand bytes per FLOP through a CU's vector-memory path, but every tile ends in 512 KiB of
-        // residual traffic, and workgroups that start together stay in lock-step -- all K loops, then all epilogues, the fabric idle
-        // half of the time.  It therefore runs these launches in TWO phase groups half a tile apart (gemm_p256.hip: stagger), on a
-        // grid that is a multiple of the column tiles (the workgroups of a row panel keep sharing its A rows): a round is
-        // p256_split_round(nt_n256) tiles.  Measured (profiles/r04/gemm_split_bench_*.log): it pays from `P256_SPLIT_MIN_ROUNDS`
-        // full rounds on (the edge nets); below that -- and for the rows beyond the last full round unless that round is well
-        // filled -- the pipelined 128 x 128 kernel (gemm_split.hip) runs them.
+        // split-residual launches (out-proj / FFN2; 8 B of residual traffic per output element next to 2 K FLOP): what bounds them
+        // is the bytes a CU has to pull through its vector-memory path -- operands AND residual -- and a 256 x 256 tile needs the
+        // fewest per FLOP; but its epilogue is a serial tail of every tile (nothing of the next tile's K loop fits beside 128
+        // accumulator registers), so with few tiles per CU the round quantisation eats the advantage.  Measured
+        // (profiles/r04/gemm_split_bench_sweep.log): from ~2.5 rounds of tiles on the 256 kernel wins (M = 61 440: 141 vs 163 us for
+        // FFN2; M = 138 752: 311 vs 357 us), below that the pipelined 128 x 128 kernel (gemm_split.hip) does (M = 30 720: 74 vs
+        // 85-89 us); the rows beyond the last full round go to the 128 kernel unless that round is well filled.  A round here is
+        // Gs = the largest multiple of the column tiles <= 256 (gemm_p256.hip: phase groups keep whole row panels).
         const int Gs = (256 / nt_n256) * nt_n256;
-        if (T < P256_SPLIT_MIN_ROUNDS * Gs) return 0;
+        if (2 * T < P256_SPLIT_MIN_HALF_ROUNDS * Gs) return 0;
         const int R = T / Gs, rem = T - R * Gs;
         if (rem == 0 || rem >= 200) return panels << 8;
         return ((R * Gs) / nt_n256) << 8;

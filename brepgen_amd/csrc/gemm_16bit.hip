@@ -333,13 +333,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 // CONV: the A operand is gathered from a conv window (implicit GEMM).  PURE (P_SPLIT only): the residual-stream form of the denoiser
 // layers -- split residual in, (hi, lo) + row statistics out, no activation, no broadcast addends, no row map -- with the
 // epilogue's run-time option checks folded away (same arithmetic, fewer instructions on the epilogue's latency chain).
-template <bool F16, int MODE, bool INSTR, bool CONV = false, bool PURE = false>
-__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels, int ng, int walk, unsigned long long* dbg,
-                                                                   int stagger = 0) {
+template <bool F16, int MODE, bool CONV = false, bool PURE = false>
+__global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
-    static_assert(!PURE || SPLIT || CONV, "PURE specialises the split-residual epilogue and the convolution epilogue (fp32 out, no activation, add_div 1, no add2)");
-    const bool k_relu = PURE ? false : g.act == BG_ACT_RELU, k_res_split = PURE ? true : g.res_hi != nullptr;
-    const bool k_add2 = PURE ? false : g.add2 != nullptr, k_stats = PURE ? true : g.stats_out != nullptr;
+    static_assert(!PURE || CONV, "PURE specialises the convolution epilogue (fp32 out, no activation, add_div 1, no add2)");
+    const bool k_relu = PURE ? false : g.act == BG_ACT_RELU, k_res_split = g.res_hi != nullptr;
+    const bool k_add2 = PURE ? false : g.add2 != nullptr, k_stats = g.stats_out != nullptr;
     const bool k_map = PURE ? false : g.row_map != nullptr;
     using E = Elem<F16>;
     using T = typename E::T;
@@ -362,23 +361,15 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
     const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, SPLIT, g.hybrid == 2) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
-    // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2).  XCD x owns the n-group
-    // x % ng (nt_n / ng column tiles: for the QKV shape the 3.5 MB of W alone would fill the L2, with ng = 2 the XCD
-    // keeps a 1.8 MB slice resident) and the row panels p == x / ng (mod 8 / ng); its G/8 workgroups walk that
-    // sub-grid column-fastest, so the ~64 concurrently running tiles of an XCD share ~7 A row panels and one W slice.
+    // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2): XCD x owns the row panels x, x + 8, ...;
+    // its G / 8 workgroups walk that sub-grid column-fastest, so the ~64 concurrently running tiles of an XCD share a few A row
+    // panels and keep W resident.  (Column groups per XCD, a row-major walk and adjacent-column pairing of the two workgroups of a
+    // CU were measured in rounds 1-2 and are flat or slower: DESIGN.md section 4.)
     const int xcd = blockIdx.x & 7, w_local = blockIdx.x >> 3, cnt = G >> 3;      // G % 8 == 0 (launcher)
-    const int gx = xcd % ng, mg = xcd / ng, mgs = 8 / ng, ngt = nt_n / ng;
-    const int first_l = xcd_remap(blockIdx.x, G);                 // walk 1: tiles first_l, first_l + G, ... in row-major order
     auto tile_at = [&](int t, int& tm0, int& tn0) -> bool {
-        if (walk == 1) {
-            const int L = first_l + ((t - w_local) / cnt) * G + p0 * nt_n;
-            tm0 = (L / nt_n) * BM;
-            tn0 = (L % nt_n) * BN;
-            return L < m_panels * nt_n;
-        }
-        const int panel = p0 + mg + (t / ngt) * mgs;
+        const int panel = p0 + xcd + (t / nt_n) * 8;
         tm0 = panel * BM;
-        tn0 = (gx * ngt + t % ngt) * BN;
+        tn0 = (t % nt_n) * BN;
         return panel < m_panels;
     };
 
@@ -457,23 +448,12 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
 
     unsigned* patch = reinterpret_cast<unsigned*>(lds + RING + wave * 4096);
     constexpr bool half_fast = FAST;
-    const bool has_res = (PURE && SPLIT) ? true : !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
+    const bool has_res = !FAST && (g.add != nullptr || (SPLIT && g.res_hi != nullptr));   // prefetched addend rows
     const int KT = g.K / G_BK;
 
     int m0, n0;
-    unsigned long long t_wait = 0, t_comp = 0, t_epi = 0, t_begin = 0, n_done = 0, t_e0 = 0, t_e1 = 0, hw_id = 0;
-    if (INSTR) t_begin = __builtin_amdgcn_s_memtime();
-    // walk 2 (A/B knob): workgroups w and w + cnt/2 of an XCD -- observed to share a CU (tools/cu_census.hip) -- take
-    // ADJACENT column tiles of one row panel, so the partner's A lines are already in the CU's vector L1
-    const int t_first = (walk == 2 && (cnt & 1) == 0) ? ((w_local % (cnt >> 1)) << 1) + (w_local / (cnt >> 1)) : w_local;
+    const int t_first = w_local;
     if (!tile_at(t_first, m0, n0)) return;
-    // Phase offset between the two workgroups of a CU (blocks b and b + G/2 share one: tools/cu_census.hip).  Launched
-    // together with identical work they run in lock-step -- both in their K loops, then both in their epilogues -- and the
-    // epilogue's store traffic never hides under the partner's MFMAs.  The second half of the grid therefore starts
-    // `stagger` x 64 cycles late (about half a tile), once per launch; the offset persists over the tile walk.
-    if (stagger > 0 && (int)blockIdx.x >= (G >> 1)) {
-        for (int r = stagger; r > 0; r -= 127) __builtin_amdgcn_s_sleep(127);
-    }
     set_src(m0, n0);
     issue(0, 0);
     int slot = 0;
@@ -517,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     // loads themselves stay unconditional and in flight together
                     const size_t o = (size_t)grow * g.ld_res + cbase + (lane & 7) * 8;
                     const int arow = (k_map && g.map_add) ? ridx[t * 2 + it] : grow;
-                    const float* ap = PURE ? nullptr : g.add + (size_t)(arow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
+                    const float* ap = g.add + (size_t)(arow / g.add_div) * g.ld_add + cbase + (lane & 7) * 8;
                     const void* p0 = k_res_split ? (const void*)(reinterpret_cast<const T*>(g.res_hi) + o) : (const void*)ap;
                     const void* p1 = k_res_split ? (const void*)(reinterpret_cast<const T*>(g.res_lo) + o) : (const void*)(ap + 4);
                     res[buf][2 * it] = *reinterpret_cast<const float4*>(p0);
@@ -557,13 +537,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
         };
         auto kstep = [&](int kt, auto last_c) {
             constexpr bool last = decltype(last_c)::value;
-            unsigned long long ta = 0;
-            if (INSTR) ta = __builtin_amdgcn_s_memtime();
             wait_vmcnt<0>();                                      // my pieces of this K-step (and older stores) done
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            unsigned long long tb = 0;
-            if (INSTR) { tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta; }
             if (!last) {
                 issue(slot ^ 1, (kt + 1) * G_BK);
             } else {
@@ -599,15 +575,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                 __builtin_amdgcn_sched_barrier(0);
             }
             slot ^= 1;
-            if (INSTR) {
-                asm volatile("s_nop 0" ::: "memory");
-                t_comp += __builtin_amdgcn_s_memtime() - tb;
-            }
         };
         for (int kt = 0; kt + 1 < KT; ++kt) kstep(kt, std::false_type{});
         kstep(KT - 1, std::true_type{});
-        unsigned long long te = 0;
-        if (INSTR) te = __builtin_amdgcn_s_memtime();
 
         // ---------------- epilogue (wave-private patch; the ring already receives the next tile) ----------------
         if (half_fast) {
@@ -788,17 +758,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                     __builtin_amdgcn_wave_barrier();
                 }
         }
-        if (INSTR) {
-            if (n_done == 0) t_e0 = te;                           // when the first / second epilogue of this workgroup began
-            if (n_done == 1) t_e1 = te;
-            t_epi += __builtin_amdgcn_s_memtime() - te; ++n_done;
-        }
         if (!has_next) break;
-    }
-    if (INSTR && dbg != nullptr && lane == 0) {
-        unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
-        o[0] = t_wait; o[1] = t_comp; o[2] = t_epi; o[3] = __builtin_amdgcn_s_memtime() - t_begin; o[4] = n_done;
-        o[5] = t_begin; o[6] = t_e0; o[7] = t_e1;
     }
 }
 
@@ -817,11 +777,28 @@ static void gemm_cost(const GemmArgs& g, double rows, double& flops, double& byt
     if (g.stats_in) bytes += 8.0 * rows * (g.K / G_BK) + 4.0 * g.N;   // LayerNorm fold: the row partials + column sums
 }
 
+// phase-group delay of a split-residual launch on the 256 x 256 kernel (bg_tune key 8: > 0 = that many x 1024 cycles, < 0 = off;
+// default: P256_SPLIT_STAGGER from P256_SPLIT_STAGGER_ROUNDS rounds of tiles on)
+static int split_stagger(const GemmArgs& g) {
+    const int t = g_tune[TUNE_GEMM_STAGGER];
+    if (t != 0) return t > 0 ? t : 0;
+    const int nt_n = g.N_pad / 256, tiles = ((g.M + 255) / 256) * nt_n;
+    return tiles >= P256_SPLIT_STAGGER_ROUNDS * ((256 / nt_n) * nt_n) ? P256_SPLIT_STAGGER : 0;
+}
+
+// Which kernel runs a 16-bit GEMM (every choice computes bit-identical results; the bg_tune keys named here exist so that the tests
+// can compare them -- key 10: 256-kernel mode, 12: split-residual kernel, 15: small-launch threshold, 8: phase-group delay):
+//   narrow outputs (N % 128 != 0: fc_out.3, conv_out)            -> generic kernel, 128 x 64 tiles
+//   < SMALL_LAUNCH_TILES tiles of 128 x 128 (batch 16)            -> generic kernel, 64 x 64 tiles, 3-deep ring
+//   16-bit output, QKV / FFN1 shapes                              -> 256 x 256 kernel on the rows that fill whole rounds (p256_rows)
+//   split-residual launches of the encoder layers                 -> 256 x 256 kernel in two phase groups from P256_SPLIT_MIN_ROUNDS
+//                                                                    rounds on, the pipelined 128 x 128 kernel (gemm_split.hip) otherwise
+//   everything else (embeds, fp32 residual stream, VAE convs)     -> 128 x 128 persistent kernel (>= 64 tiles) / generic 128 x 128
 template <bool F16>
 static int launch16(const GemmArgs& g, hipStream_t s) {
     const double rows_all = g.rows_hint > 0 ? g.rows_hint : g.M;  // (profiler accounting)
     double rows_tail = rows_all;
-    const int m128 = (g.M + 127) / 128, m256 = (g.M + 255) / 256, n128 = g.N_pad / 128;
+    const int m128 = (g.M + 127) / 128, n128 = g.N_pad / 128;
     if (g.N_pad % 128 != 0) {                                     // narrow outputs (fc_out.3: 6/18/48 -> padded 64; conv_out 3)
         double fl, by;
         gemm_cost(g, rows_all, fl, by);
@@ -835,8 +812,8 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     // time.  64 x 64 tiles (two waves, 3-deep ring: two K-steps of DMA in flight) put four times as many workgroups on the chip
     // and halve the per-step latency chain; same k order, same epilogue code -> bit-identical results
     // (tests/test_gpu_round4.py).  bg_tune key 15: tile-count threshold (0 = default, -1 = off).
-    const int small_nt = g_tune[15] < 0 ? 0 : (g_tune[15] > 0 ? g_tune[15] : SMALL_LAUNCH_TILES);
-    if (g_tune[TUNE_GEMM_VARIANT] == 0 && g.cv_C == 0 && nt < small_nt && (g.stats_in == nullptr || g.K / G_BK <= 16)) {
+    const int small_nt = g_tune[TUNE_SMALL_TILES] < 0 ? 0 : (g_tune[TUNE_SMALL_TILES] > 0 ? g_tune[TUNE_SMALL_TILES] : SMALL_LAUNCH_TILES);
+    if (g.cv_C == 0 && nt < small_nt && (g.stats_in == nullptr || g.K / G_BK <= 16)) {
         double fl, by;
         gemm_cost(g, rows_all, fl, by);
         ProfScope prof(PK_GEMM_BF16_64, fl, by, s);
@@ -848,26 +825,24 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
                                (g.row_map == nullptr || (g.out_lo != nullptr && !g.map_out));   // mapped addends: SPLIT epilogue only
     // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
     //  persistent and the generic kernel implement them, with bit-identical arithmetic)
-    const int variant = g_tune[TUNE_GEMM_VARIANT];                // 0 = shipped; others are A/B baselines
-    if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in || variant != 0)) {
+    if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in)) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;
     }
-    // 256 x 256 persistent kernel (gemm_p256.hip) for the MFMA-bound 16-bit-output GEMMs, on the row panels that fill complete
-    // rounds of 256 tiles; the 128 x 128 kernel below runs the remaining rows (bg_common.h: p256_rows).  With a device-side row
-    // count the split is only known on the device: both kernels are launched and evaluate the same rule.
-    // bg_tune key 10: 0 = hybrid, 1 = 256 kernel alone wherever eligible, 2 = never.
+    // 256 x 256 persistent kernel (gemm_p256.hip) on the row panels that fill complete rounds of tiles; a 128 x 128 kernel below
+    // runs the remaining rows (bg_common.h: p256_rows).  With a device-side row count the split is only known on the device: both
+    // kernels are launched and evaluate the same rule.  bg_tune key 10: 0 = hybrid, 1 = 256 kernel alone wherever eligible, 2 = never.
     bool tail_only = false;
-    if (variant == 0 && g_tune[TUNE_P256_MODE] != 2 && p256_eligible(g)) {
+    if (g_tune[TUNE_P256_MODE] != 2 && p256_eligible(g)) {
         double fl, by;
+        const bool split = g.out_lo != nullptr;
         if (g_tune[TUNE_P256_MODE] == 1) {
             gemm_cost(g, rows_all, fl, by);
             ProfScope prof(PK_GEMM_P256, fl, by, s);
             GemmArgs h = g;
-            if (g.out_lo) h.p256_stagger = g_tune[TUNE_GEMM_STAGGER] > 0 ? g_tune[TUNE_GEMM_STAGGER] : (g_tune[TUNE_GEMM_STAGGER] < 0 ? 0 : P256_SPLIT_STAGGER);
+            if (split) h.p256_stagger = split_stagger(g);
             return launch_p256<F16>(h, s);
         }
-        const bool split = g.out_lo != nullptr;
         // upper bound of what the 256 kernel may own (a device-side row count can only be smaller: the split rule is not monotonic,
         // so with one the launch happens whenever ANY row count up to the bound could give it rows)
         const int hmode = g.concurrent ? 2 : 1;
@@ -880,7 +855,7 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         if (rows_hi > 0 && can_tail) {
             GemmArgs h = g;
             h.hybrid = hmode;
-            if (split) h.p256_stagger = g_tune[TUNE_GEMM_STAGGER] > 0 ? g_tune[TUNE_GEMM_STAGGER] : (g_tune[TUNE_GEMM_STAGGER] < 0 ? 0 : P256_SPLIT_STAGGER);
+            if (split) h.p256_stagger = split_stagger(g);
             const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split, hmode == 2), rows_all);
             rows_tail = rows_all - rows_p;
             gemm_cost(g, rows_p, fl, by);
@@ -900,56 +875,31 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     double fl_t, by_t;
     gemm_cost(g, rows_tail, fl_t, by_t);
     // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes the rows the 256 x 256
-    // kernel does not (bg_tune key 12 = 1: the 128 x 128 persistent kernel instead, kept for the bit-equality test and A/B timing)
-    if (variant == 0 && g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g_)) {
+    // kernel does not (bg_tune key 12 = 1: the 128 x 128 persistent kernel's split epilogue instead, for the bit-equality tests)
+    if (g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g_)) {
         ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
         return launch_split_pipe<F16>(g_, s);
     }
-    ProfScope prof(g.N_pad % 128 == 0 ? PK_GEMM_BF16_128 : PK_GEMM_BF16_64, fl_t, by_t, s);
-    if (variant == 10 || !persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128x128, 2-stage ring
+    ProfScope prof(PK_GEMM_BF16_128, fl_t, by_t, s);
+    if (!persistent_ok || (g.stats_in && g.K != FOLD_PARTS * G_BK)) {   // non-persistent 128 x 128, 2-stage ring
         hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(m128 * n128), dim3(256), 0, s, g_);
-    } else if (variant == 5) {                                    // 128x128, 8 waves (32x64 per wave), 4 waves per SIMD
-        hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 4, 2, 2>), dim3(m128 * n128), dim3(512), 0, s, g_);
-    } else if (variant == 6 && g.N_pad % 256 == 0) {              // 256x256, 8 waves (128x64 per wave), 2-stage ring
-        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 256, 2, 4, 2>), dim3(m256 * (g.N_pad / 256)), dim3(512), 0, s, g_);
-    } else if (variant == 2) {                                    // 256x128, 8 waves, 3-stage ring
-        hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g_);
     } else {
-        // 2 resident workgroups per CU x 256 CUs, multiple of 8.  (bg_tune key 3 caps it -- 256 = one workgroup per CU, so
-        // that the GEMM of a second, independent stream can be co-resident: tools/dual_stream_probe.py)
-        const int cap = (g_tune[3] >= 8 && g_tune[3] <= 512) ? (g_tune[3] & ~7) : 512;
-        const int grid = nt < cap ? (nt & ~7) : cap;
-        // column groups per launch (bg_tune_set key 4).  Measured on the QKV shape (W = 3.5 MB vs a 4 MB L2 per XCD):
-        // ng = 2 is not faster than ng = 1 once the clocks are warm, so 1 is shipped.
-        int ng = g_tune[4] > 0 ? g_tune[4] : 1;
-        if (n128 % ng != 0 || (ng != 1 && ng != 2 && ng != 4 && ng != 8)) ng = 1;
+        const int grid = nt < 512 ? (nt & ~7) : 512;              // 2 resident workgroups per CU x 256 CUs, a multiple of 8
         const bool fast = g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.out_lo == nullptr;
-        unsigned long long* none = nullptr;
-        // phase offset of the second workgroup of every CU (bg_tune key 8: sleep units of 64 cycles; 0 = off), only when a
-        // workgroup walks enough tiles for the one-off delay to pay
-        const int stg = (grid == 512 && nt >= 4 * 512) ? g_tune[TUNE_GEMM_STAGGER] : 0;
-        if (variant == 31 && g.stats_in == nullptr) {             // s_memtime phase accounting (tools/gemm_instr.py)
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(
-                ((unsigned long long)(unsigned)g_tune[2] << 32) | (unsigned)g_tune[1]);
-            if (g.out_lo) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
-            else if (fast) hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
-            else hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], dbg, stg);
-        } else if (g.cv_C > 0 && g.act == BG_ACT_NONE && !g.add2 && g.add_div == 1 && g_tune[14] != 1) {
-            // implicit-GEMM convolution as the VAE passes issue it: fp32 output (+ fp32 residual of the same shape), options folded away
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
-        } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution: fp32 output (+ fp32 residual)
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
-        } else if (g.out_lo && g.res_hi && g.stats_out && !g.add && !g.add2 && !g.row_map && g.act == BG_ACT_NONE && g_tune[14] != 1) {
-            // the residual-stream GEMMs of the denoiser layers (bg_tune key 14 = 1: the general split instantiation, for A/B)
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false, false, true>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+        if (g.cv_C > 0 && g.act == BG_ACT_NONE && !g.add2 && g.add_div == 1) {
+            // implicit-GEMM convolution as the VAE passes issue it: fp32 output (+ fp32 residual of the same shape), the run-time
+            // options of the general epilogue folded away (904 -> 242 VALU instructions per tile epilogue; -4.5 % per decode pass)
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true, true>), dim3(grid), dim3(256), 0, s, g_, m128);
+        } else if (g.cv_C > 0) {                                  // implicit-GEMM convolution, any other option set
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true>), dim3(grid), dim3(256), 0, s, g_, m128);
         } else if (g.out_lo) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_SPLIT>), dim3(grid), dim3(256), 0, s, g_, m128);
         } else if (g.stats_in) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_FOLD16>), dim3(grid), dim3(256), 0, s, g_, m128);
         } else if (fast) {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_PLAIN16>), dim3(grid), dim3(256), 0, s, g_, m128);
         } else {
-            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, false>), dim3(grid), dim3(256), 0, s, g_, m128, ng, g_tune[5], none, stg);
+            hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL>), dim3(grid), dim3(256), 0, s, g_, m128);
         }
     }
     return launch_status("gemm16");

@@ -57,7 +57,7 @@ __device__ __forceinline__ int opaque(int x) {
     return x;
 }
 
-template <bool F16, int MODE, bool STATS = false, int ACT = -1>   // ACT: the activation as a compile-time constant (-1: g.act at run time)
+template <bool F16, int MODE, bool STATS = false, int ACT = BG_ACT_NONE>   // ACT: the activation, a compile-time constant (plain / fold epilogues)
 __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     constexpr bool FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
     static_assert(MODE == P_PLAIN16 || MODE == P_FOLD16 || MODE == P_SPLIT, "16-bit output epilogues only");
@@ -82,11 +82,12 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     int L = xcd_remap(blockIdx.x, G);
     if (L >= T_all) return;                                       // uniform per workgroup, before any barrier
     if constexpr (SPLIT) {
-        // Two phase groups.  A split tile is ~12 us of K loop (operands out of the L2, the fabric idle) and then 512 KiB of residual
-        // traffic per CU; workgroups that start together stay together, so the chip alternates between "no memory traffic" and
-        // "every CU waiting for memory".  The workgroups of every second row panel (the grid is a multiple of the column tiles:
-        // the nt_n workgroups that share a panel's A rows stay in one group, round after round) start `p256_stagger` x 1024 cycles
-        // late -- about one K loop -- so one group's epilogues run under the other group's K loops.
+        // Two phase groups (long launches only: the launcher sets p256_stagger from 5 rounds of tiles on).  Workgroups that start
+        // together stay together -- every CU in its K loop, then every CU in its 512 KiB of residual traffic.  The workgroups of
+        // every second row panel (the grid is a multiple of the column tiles: the nt_n workgroups that share a panel's A rows stay in
+        // one group, round after round) start `p256_stagger` x 1024 cycles late, about one K loop.  The measured effect is small
+        // (+1-3 % at 6-8 rounds, a loss at 1-3: profiles/r04/gemm_split_bench_sweep.log): the epilogue is a per-wave latency chain
+        // (three vmcnt(0) drains per tile), not a fabric burst -- which is what the experiment was for.
         if (g.p256_stagger > 0 && (((unsigned)L / (unsigned)nt_n) & 1u))
             for (int r = g.p256_stagger; r > 0; --r) __builtin_amdgcn_s_sleep(16);
     }
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
     const unsigned grp_lds = lds0 + (unsigned)(P256_RING + wm * 4 * P256_PATCH);
     const unsigned char* grp = lds + P256_RING + wm * 4 * P256_PATCH;
     const bool has_bias = g.bias != nullptr;
-    const bool relu = ACT < 0 ? g.act == BG_ACT_RELU : ACT == BG_ACT_RELU;
+    // (a run-time test costs the plain / fold epilogues a v_max + v_cndmask per accumulator element; the split epilogue keeps one --
+    //  always false there, p256_eligible -- because with the constant hipcc's register allocation moves and three dwords spill)
+    const bool relu = SPLIT ? g.act == BG_ACT_RELU : ACT == BG_ACT_RELU;
 
     // ---- LDS-DMA: wave w moves pieces w and w + 8 (8 rows x 128 B each) of every 128-row half-tile ----
     // Source = wave-uniform base (SGPR pair: tile origin + k offset + half offset) + 32-bit per-lane byte offset; the 16-byte chunk
@@ -514,6 +517,7 @@ bool p256_eligible(const GemmArgs& g) {
           g.out_dtype != BG_F32 && g.add == nullptr && g.add2 == nullptr && g.row_map == nullptr && g.cv_C == 0 &&
           (size_t)255 * g.lda * 2 + 128 < 0xffffffffull && (size_t)255 * g.K * 2 + 128 < 0xffffffffull))
         return false;
+    if (g.act != BG_ACT_NONE && (split || g.act != BG_ACT_RELU)) return false;     // activations compiled in: none / ReLU (split: none)
     if (split)          // split residual stream in place (out-proj / FFN2): residual planes required, no LayerNorm fold on top
         return !fold && g.res_hi != nullptr && g.res_lo != nullptr && g.ld_res % 8 == 0 && (size_t)g.M * g.ld_res * 2 < 0xffffffffull;
     return g.res_hi == nullptr && g.stats_out == nullptr &&
@@ -531,17 +535,13 @@ int launch_p256(const GemmArgs& g, hipStream_t s) {
         const int nt_n = g.N_pad / 256;
         grid = grid / nt_n * nt_n;
     }
-    // (bg_tune key 13 = 1: the instantiations that test g.act at run time, for the A/B)
-    const bool ct = g_tune[13] != 1, none = ct && g.act == BG_ACT_NONE, relu = ct && g.act == BG_ACT_RELU;
-    // (the split epilogue keeps the run-time check: with the constant its register allocation moves and three dwords spill)
+    const bool relu = g.act == BG_ACT_RELU;                       // (p256_eligible: act is none or ReLU; split launches: none)
     if (g.out_lo && g.stats_out) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, true>), dim3(grid), dim3(512), 0, s, g);
     else if (g.out_lo) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_SPLIT, false>), dim3(grid), dim3(512), 0, s, g);
-    else if (g.stats_in && none) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
     else if (g.stats_in && relu) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false, BG_ACT_RELU>), dim3(grid), dim3(512), 0, s, g);
-    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16>), dim3(grid), dim3(512), 0, s, g);
-    else if (none) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
+    else if (g.stats_in) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_FOLD16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
     else if (relu) hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false, BG_ACT_RELU>), dim3(grid), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16>), dim3(grid), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm16_p256_kernel<F16, P_PLAIN16, false, BG_ACT_NONE>), dim3(grid), dim3(512), 0, s, g);
     return launch_status("gemm16_p256");
 }
 template int launch_p256<false>(const GemmArgs&, hipStream_t);

@@ -381,8 +381,12 @@ typedef struct {
 int bg_profile_begin(int max_launches);
 int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number of rows written (<0: error) */
 
-/* Kernel-selection knob for A/B measurements (key 0: 16-bit GEMM tile/pipeline variant, 0 = shipped default;
- * key 10: the 256 x 256 persistent kernel -- 0 = the library's 256 + 128 partition, 1 = alone, 2 = never). */
+/* Kernel-selection knobs.  Every choice computes bit-identical results: the keys exist so that the parity tests can run the same
+ * GEMM on each kernel that may serve it (0 always = the library's own choice; process-global, not for production use).
+ *   key  8  split-residual launches on the 256 x 256 kernel: start delay of the second phase group, x 1024 cycles (< 0: none)
+ *   key 10  256 x 256 persistent kernel: 1 = alone wherever eligible, 2 = never
+ *   key 12  split-residual GEMMs of the encoder layers: 1 = the 128 x 128 persistent kernel instead of the pipelined one
+ *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off) */
 int bg_tune_set(int key, int value);
 
 /* How a 16-bit GEMM launch of `rows` x `n_cols` (n_cols a multiple of 256) is partitioned between the 256 x 256

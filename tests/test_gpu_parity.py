@@ -213,7 +213,10 @@ def test_denoiser_fp32_vs_reference_golden(pc, name):
 # (profiles/r04/parity_r04.json, key golden_bf16_<case>; the values differ per case with |eps| and the token count).  north_star's
 # "1e-3 bf16" is NOT met on eps itself -- by construction: 8 mantissa bits through 12 layers, the reference's own bf16 autocast sits
 # at 2.4-3.3e-2 -- it is asserted where it is meaningful, on the per-step sample update (test_baseline_config0_ddpm_chain).
-GOLDEN_BF16_BOUND = {"_default": (4e-2, 8e-3)}
+GOLDEN_BF16_BOUND = {"_default": (4e-2, 8e-3),
+                     "edgepos_b2_s6_e5": (1.6e-2, 4.6e-3), "edgez_b2_s7_e9": (2.2e-2, 5.5e-3), "edgez_cf_b2_s4_e40": (2.6e-2, 5.7e-3),
+                     "surfpos_b2_n30": (2.1e-2, 5.9e-3), "surfpos_cf_b2_n60": (2.5e-2, 6.8e-3), "surfz_b3_n60": (2.3e-2, 5.4e-3),
+                     "surfz_cf_b2_n17": (2.9e-2, 7.2e-3)}
 
 
 @pytest.mark.parametrize("name", GOLDEN)

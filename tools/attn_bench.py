@@ -46,11 +46,8 @@ for B, N, dt in [(256, 1800, torch.bfloat16), (64, 4000, torch.bfloat16), (128, 
     for name, (kp, of, pairs) in cases.items():
         res = {}
         for rnd in range(2):
-            for variant in ((1, 0) if N > 64 else (0,)):
-                lib.bg_tune_set(6, variant)
-                us = timed(lambda: call(kp, of), 5 if N > 64 else 20)
-                res.setdefault("old" if variant else "new", []).append(us)
-        lib.bg_tune_set(6, 0)
+            us = timed(lambda: call(kp, of), 5 if N > 64 else 20)
+            res.setdefault("new", []).append(us)
         row = {"B": B, "N": N, "dtype": str(dt)[6:], "case": name,
                **{k: {"us": round(min(v), 1), "tflops_executed": round(4.0 * 12 * 64 * pairs / min(v) / 1e6, 1)} for k, v in res.items()}}
         rows.append(row)
