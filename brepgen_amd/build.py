@@ -32,6 +32,12 @@ def _digest():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     h.update(" ".join(FLAGS).encode())
+    # the compiler is part of the build: the kernels that run at the 256-VGPR limit (gemm_p256.hip, gemm_split.hip) are checked for
+    # spills with THIS hipcc (tests/test_abi_cpu.py); another version has to rebuild -- and re-run that check
+    try:
+        h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.encode())
+    except OSError:
+        pass
     return h.hexdigest()
 
 

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                 // way back a lane owns 8 consecutive columns of a row, so the residual arrives and hi / lo leave as 16-byte
                 // accesses of whole 128-byte lines, and one 8-lane butterfly gives the row's (sum, sum of squares) -- the
                 // arithmetic, its order and the statistics layout of the 128 x 128 kernel (gemm_16bit.hip), bit for bit.
-                // The residual loads are inline asm and waited for with vmcnt(0) BEFORE the first store that follows them: the
+                // The residual loads are waited for with an explicit vmcnt(0) BEFORE the first store that follows them: the
                 // vector-memory counter is shared by loads and stores and the two classes retire out of order with respect to each
                 // other (a counted wait with younger stores passed early under load: measured, profiles/r03/gemm_p256_split_*.log),
                 // so a wave can only wait for a load issued after a store by waiting for that store as well.  Hence three batches
@@ -350,8 +350,10 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                         int grow = rbase + t * 16 + it * 8 + r8;
                         grow = grow < Mv ? grow : Mv - 1;
                         const unsigned voff = (unsigned)grow * (unsigned)g.ld_res * 2u + col_b;
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbuf[t][it][0]) : "v"(voff), "s"(rh) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbuf[t][it][1]) : "v"(voff), "s"(rl) : "memory");
+                        // (compiler-visible loads: hipcc knows the destinations are pending and adds its own wait in front of
+                        //  res_wait's register pins -- after the explicit vmcnt(0) there, where it costs nothing)
+                        rbuf[t][it][0] = *reinterpret_cast<const u32x4*>(rh + voff);
+                        rbuf[t][it][1] = *reinterpret_cast<const u32x4*>(rl + voff);
                     }
                 };
                 auto res_wait = [&](int t0, int t1) {                // every load issued so far has landed (slabs t0 .. t1 - 1)
