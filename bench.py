@@ -532,18 +532,38 @@ def main():
                          "tflops": round(r["flops"] / r["total_ms"] / 1e9, 1) if r["flops"] else None,
                          "gbs": round(r["bytes"] / r["total_ms"] / 1e6, 1)} for k, r in rows.items()}
         dom = max(rows.values(), key=lambda r: r["total_ms"])
-        ach = dom["flops"] / dom["total_ms"] / 1e9                    # TFLOP/s = flops per launch / avg duration
+        # which roofline bounds the dominant kernel: its arithmetic intensity (algorithmic FLOPs / algorithmic bytes of its
+        # launches) against the ridge MFMA peak / HBM peak = 312 FLOP/B.  QKV / FFN1 (567 / 427 FLOP/B) are MFMA-bound; the
+        # residual-stream GEMMs (out-proj / FFN2 with the split residual: 153 / 192 FLOP/B -- 8 B of residual traffic per output
+        # element) and every elementwise kernel are HBM-bound and are judged as GB/s.
+        ridge = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        intensity = dom["flops"] / dom["bytes"] if dom["bytes"] else float("inf")
         traffic, traffic_src = pmc_traffic(dom["kernel"], dom["launches"] / args.steps)
-        roofline = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        if intensity >= ridge:
+            ach = dom["flops"] / dom["total_ms"] / 1e9                # TFLOP/s = flops per launch / avg duration
+            bound, peak, unit = "mfma", MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach = dom["bytes"] / dom["total_ms"] / 1e6                # GB/s = algorithmic bytes per launch / avg duration
+            bound, peak, unit = "hbm", HBM_PEAK_GBS, "GB/s"
+        roofline = {"kernel": dom["kernel"], "bound": bound, "achieved": round(ach, 1), "peak": peak,
+                    "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_over_algorithmic_bytes": round(traffic / (dom["bytes"] / dom["launches"]), 3) if traffic else None,
                     "traffic_measured_on": traffic_src,
+                    "arithmetic_intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                     "launches_per_step": round(dom["launches"] / args.steps, 2),
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
+                    "tflops": round(dom["flops"] / dom["total_ms"] / 1e9, 1), "gbs": round(dom["bytes"] / dom["total_ms"] / 1e6, 1),
                     "flops": "executed (valid rows only) over the launches of the three loops",
                     "measured_with": "launches serialised (n_split = 1); the timed region runs n_split = %d" % n_split}
+        # the two largest kernels side by side (they trade places from box to box: ~1.3 ms per step each)
+        roofline["by_kernel"] = {
+            k: {"ms_per_step": round(r["total_ms"] / args.steps, 4),
+                "bound": "mfma" if (r["bytes"] and r["flops"] / r["bytes"] >= ridge) else "hbm",
+                "frac_of_mfma_peak": round(r["flops"] / r["total_ms"] / 1e9 / MFMA_PEAK_TFLOPS, 4),
+                "frac_of_hbm_peak": round(r["bytes"] / r["total_ms"] / 1e6 / HBM_PEAK_GBS, 4)}
+            for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"])[:4] if r["flops"]}
         # every GEMM kernel of the step together (the 256 x 256 kernel takes the row panels that fill whole rounds, the
         # 128 x 128 kernel the rest and the residual-stream GEMMs): executed FLOPs / their summed durations
         gem = [r for k, r in rows.items() if k.startswith("gemm16")]

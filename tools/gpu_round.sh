@@ -1,0 +1,50 @@
+#!/bin/bash
+# One gpurun call: GPU tests, smoke, bench, rocprofv3 kernel stats, PMC passes, the rank-local ABC / furniture loops in full.
+# Everything lands in gpurun_out/.     bash tools/gpu_round.sh [all|test|bench|prof|pmc|ranklocal]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+WHAT=${1:-all}
+PMC_STEPS=40; PMC_WARMUP=3        # the step mix bench.py's roofline.traffic is compared against (tools/pmc_summary.py <round> 40 3)
+if [[ $WHAT == all || $WHAT == test ]]; then
+  timeout 1300 python -m pytest tests -m gpu -q --durations=25 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+  tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log
+fi
+if [[ $WHAT == all || $WHAT == bench ]]; then
+  timeout 900 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
+  tail -2 $O/bench.log | cut -c1-260
+fi
+if [[ $WHAT == all || $WHAT == prof ]]; then
+  export TMPDIR=/tmp
+  cd /tmp
+  # the bench command as the driver runs it (product default: two sample groups in flight), and with serialised launches
+  for sp in 0 1; do
+    rm -rf $O/prof_stats_split$sp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_split$sp -o bench -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-extra --split $sp > $O/prof_stats_split$sp.log 2>&1
+    echo "rocprof stats (split $sp) rc=$?" >> $O/prof_stats_split$sp.log
+  done
+  cd $R
+fi
+if [[ $WHAT == all || $WHAT == pmc ]]; then
+  export TMPDIR=/tmp
+  cd /tmp
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rm -rf $O/pmc$i
+    timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc$i -o pmc -- python $R/bench.py --steps $PMC_STEPS --warmup $PMC_WARMUP --no-cpu-baseline --no-roofline --no-extra --split 1 > $O/pmc$i.log 2>&1
+    echo "pmc$i rc=$? ($set)" >> $O/pmc$i.log
+  done
+  cd $R
+fi
+if [[ $WHAT == all || $WHAT == ranklocal ]]; then
+  for c in cfg4 cfg5; do
+    timeout 900 python tools/rank_local_bench.py $c > $O/rank_local_$c.log 2>&1; echo "rc=$?" >> $O/rank_local_$c.log
+    grep -E "loops_s|samples_per_s" $O/rank_local_$c.log
+  done
+fi
+du -ah $O | sort -h | tail -30 > $O/listing.txt 2>&1
+find $O -type f -size +8M -print -delete >> $O/listing.txt 2>&1
