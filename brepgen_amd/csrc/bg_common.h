@@ -130,6 +130,11 @@ struct GemmArgs {
     // ---- 256 + 128 hybrid (set by the launcher only): rows [0, p256_rows(*m_dev, N_pad / 256)) belong to the 256 x 256 kernel,
     // the rest to the 128 x 128 kernel -- both evaluate the same rule on the device-side row count ----
     int hybrid = 0;                   // 1: the split above; 2: all-or-nothing (concurrent sample groups, see p256_rows)
+    // the number of rows the 256 x 256 kernel owns in a hybrid launch: known on the host (rows256_host) or, with a device-side row
+    // count, read from the table compact_rows left behind (rule_table: set by the caller of gemm(); rows256_dev: the launch's entry)
+    const int* rule_table = nullptr;
+    const int* rows256_dev = nullptr;
+    int rows256_host = 0;
     int p256_stagger = 0;             // split-residual launches of the 256 x 256 kernel: start delay of the second phase group, x 1024 cycles
     int concurrent = 0;               // caller's hint: other launches of the same kind are in flight on sibling streams
 };
@@ -137,18 +142,37 @@ struct GemmArgs {
 // Tile-round quantisation: one 256 x 256 tile per CU and round, so a launch whose tile count is a little
 // above a multiple of 256 would spend a whole round on a few tiles.  The 256 kernel therefore takes the whole row panels that
 // fill complete rounds (or everything when the last round is at least P256_TAIL_MIN tiles full); the 128 x 128 kernel -- four
-// times finer, two workgroups per CU -- takes the remaining rows.  Evaluated identically by both kernels and by the host.
+// times finer, two workgroups per CU -- takes the remaining rows.  Evaluated on the host when the row count is known there, and
+// otherwise ONCE on the device, by the compaction kernel that produces the row count (compact.hip: a table of P256_RULE_ENTRIES
+// answers, one per (column tiles, split epilogue, all-or-nothing)); the GEMM kernels only read their entry.
 constexpr int P256_TAIL_MIN = 160;
+constexpr int P256_RULE_ENTRIES = 12;          // rule table: index = (column-tile class {3, 4, 9}) * 4 + split * 2 + all_or_nothing
+__host__ __device__ inline int p256_rule_index(int nt_n256, bool split, bool all_or_nothing) {
+    const int c = nt_n256 == 3 ? 0 : (nt_n256 == 4 ? 1 : (nt_n256 == 9 ? 2 : -1));      // 768 / 1024 / 2304 columns
+    return c < 0 ? -1 : c * 4 + (split ? 2 : 0) + (all_or_nothing ? 1 : 0);
+}
 constexpr int P256_SPLIT_STAGGER = 24;         // start delay of the second phase group of a split-residual launch, x 1024 cycles ...
 constexpr int P256_SPLIT_STAGGER_ROUNDS = 5;   // ... from this many rounds on (+1-3 % there, a loss below: profiles/r04/gemm_split_bench_sweep.log)
 constexpr int P256_SPLIT_MIN_HALF_ROUNDS = 5;  // split-residual launches: the 256 x 256 kernel from 2.5 rounds of tiles on
+// split-residual launches: the rule on whole rounds of Gs = (256 / nt_n256) * nt_n256 tiles (see p256_rows)
+__host__ __device__ inline int p256_split_rows(int panels, int nt_n256, bool all_or_nothing) {
+    const int q = 256 / nt_n256;                                  // row panels per round
+    const int Gs = q * nt_n256, T = panels * nt_n256;
+    if (T <= Gs) return T >= 200 ? panels << 8 : 0;             // one well-filled round (the compacted face batch: 204 tiles, 40 vs 45 us)
+    if (2 * T < P256_SPLIT_MIN_HALF_ROUNDS * Gs) return 0;
+    if (all_or_nothing) return panels << 8;
+    const int R = panels / q;                                     // full rounds (T / Gs == panels / q)
+    const int rem = T - R * Gs;
+    if (rem == 0 || rem >= 200) return panels << 8;
+    return (R * q) << 8;
+}
 __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = false, bool all_or_nothing = false) {
     const int panels = (rows + 255) >> 8, T = panels * nt_n256;
     if (all_or_nothing) {
         // Several sample groups in flight on forked streams (n_split > 1): a partial round of one group's launch is filled by the
         // other group's, and a tail kernel only adds a dependent launch to each chain -- the 256 kernel runs alone or not at all
         // (measured, profiles/r03/face_ldm_legs_ab_p256.log: leg B 4.17 vs 4.41 ms with the tail kernels)
-        if (split) return 2 * T >= P256_SPLIT_MIN_HALF_ROUNDS * ((256 / nt_n256) * nt_n256) ? panels << 8 : 0;
+        if (split) return p256_split_rows(panels, nt_n256, true);
         // (non-split threshold: 300 vs 400 tiles measured on the compacted face batch, 2 x 306 QKV tiles in flight: -1.4 % per step,
         //  profiles/r03/face_ldm_legs_ab_fold_in_kernel.log)
         return (T >= 300 || (T >= 200 && T <= 256)) ? panels << 8 : 0;
@@ -162,11 +186,7 @@ __host__ __device__ inline int p256_rows(int rows, int nt_n256, bool split = fal
         // FFN2; M = 138 752: 311 vs 357 us), below that the pipelined 128 x 128 kernel (gemm_split.hip) does (M = 30 720: 74 vs
         // 85-89 us); the rows beyond the last full round go to the 128 kernel unless that round is well filled.  A round here is
         // Gs = the largest multiple of the column tiles <= 256 (gemm_p256.hip: phase groups keep whole row panels).
-        const int Gs = (256 / nt_n256) * nt_n256;
-        if (2 * T < P256_SPLIT_MIN_HALF_ROUNDS * Gs) return 0;
-        const int R = T / Gs, rem = T - R * Gs;
-        if (rem == 0 || rem >= 200) return panels << 8;
-        return ((R * Gs) / nt_n256) << 8;
+        return p256_split_rows(panels, nt_n256, false);
     }
     const int R = T >> 8, rem = T - (R << 8);
     if (rem == 0 || rem >= P256_TAIL_MIN) return panels << 8;
@@ -250,7 +270,7 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
 // valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
 // covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),
 // src_row [B * n_mask * rep]: padded-layout index of every compact row, in order.
-int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s);
+int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s, int* rule = nullptr);
 int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
 // c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)
 int cond_vector(const float* temb, int nt, const float* class_embed, const int64_t* label, float* c, int B,

@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const uint8_t* __restr
 }
 
 // exclusive scan of counts[0..B) -> offsets[0..B]; one block, B <= a few thousand
-__global__ __launch_bounds__(1024) void scan_offsets_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets) {
+// rule (optional, P256_RULE_ENTRIES ints): how the GEMM launches of this evaluation split their rows between the 256 x 256 kernel
+// and a 128 x 128 kernel, evaluated HERE once per row count -- the GEMM kernels then read one int instead of each carrying the rule
+__global__ __launch_bounds__(1024) void scan_offsets_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
+                                                            int* __restrict__ rule) {
     __shared__ int buf[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -50,6 +53,10 @@ __global__ __launch_bounds__(1024) void scan_offsets_kernel(const int* __restric
         __syncthreads();
     }
     if (threadIdx.x == 0) offsets[B] = carry;
+    if (rule != nullptr && threadIdx.x < P256_RULE_ENTRIES) {
+        const int nt = threadIdx.x >> 2 == 0 ? 3 : (threadIdx.x >> 2 == 1 ? 4 : 9);
+        rule[threadIdx.x] = p256_rows(carry, nt, (threadIdx.x & 2) != 0, (threadIdx.x & 1) != 0);
+    }
 }
 
 // src_row[offsets[b] + j] = padded-layout index of the j-th valid token of sample b (order preserved)
@@ -80,11 +87,11 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const uint8_t* __restric
     }
 }
 
-int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s) {
+int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s, int* rule) {
     ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * (2.0 + 4.0 * rep), s);
     // counts live in src_row's tail?  no: keep it simple -- offsets[1..B] doubles as the count buffer before the scan
     hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, rep, offsets + 1);
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, s, offsets + 1, B, offsets);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, s, offsets + 1, B, offsets, rule);
     hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, rep, offsets, src_row);
     return launch_status("compact_rows");
 }
@@ -94,5 +101,5 @@ int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, 
 extern "C" int bg_compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, bg_stream_t stream) {
     BG_REQUIRE(mask && offsets && src_row, BG_E_ARG, "bg_compact_rows: null pointer");
     BG_REQUIRE(B > 0 && n_mask > 0 && rep > 0, BG_E_SHAPE, "bg_compact_rows: empty shape");
-    return bg::compact_rows(mask, B, n_mask, rep, offsets, src_row, (hipStream_t)stream);
+    return bg::compact_rows(mask, B, n_mask, rep, offsets, src_row, (hipStream_t)stream, nullptr);
 }

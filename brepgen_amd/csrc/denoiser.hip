@@ -79,7 +79,7 @@ static Workspace plan(int net, int B, int S, int E, int dtype) {
     w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
     w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
     w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.M * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
-    w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2) * 4) + align_up((size_t)w.M * 4) : 0;   // var-len: offsets, row map
+    w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2 + P256_RULE_ENTRIES) * 4) + align_up((size_t)w.M * 4) : 0;   // var-len: offsets + GEMM partition table, row map
     w.total = o;
     return w;
 }
@@ -104,6 +104,7 @@ struct Ctx {
     const int* m_dev = nullptr;       // device-side row count (offsets[B])
     const int* src_row = nullptr;     // compact row -> padded-layout token index
     const int* offsets = nullptr;     // per-sample first row, [B+1]
+    const int* rule = nullptr;        // 256 / 128 kernel partition of the GEMM launches for this row count (compact.hip)
     int N_tok = 1;                    // tokens per sample of the padded layout
     double rows_hint = 0.0, pairs_hint = 0.0;   // host-side estimates: GEMM kernel choice + profiler accounting (brepgen_hip.h)
     int concurrent = 0;               // sibling sample groups are in flight on forked streams (n_split > 1)
@@ -197,11 +198,11 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     c.concurrent = concurrent ? 1 : 0;
     if (varlen) {
         int* offs = reinterpret_cast<int*>(c.ws + c.p.off_rows);
-        int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2) * 4));
+        int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2 + P256_RULE_ENTRIES) * 4));
         const int n_mask = (net == BG_EDGEPOS) ? S : N, rep = (net == BG_EDGEPOS) ? E : 1;
-        int rcc = compact_rows(in->mask, B, n_mask, rep, offs, srow, s);
+        int rcc = compact_rows(in->mask, B, n_mask, rep, offs, srow, s, offs + B + 2);
         if (rcc) return rcc;
-        c.offsets = offs; c.m_dev = offs + B; c.src_row = srow;
+        c.offsets = offs; c.m_dev = offs + B; c.src_row = srow; c.rule = offs + B + 2;
         c.rows_hint = in->rows_hint > 0 ? in->rows_hint : 0.0;
         c.pairs_hint = in->pairs_hint > 0 ? in->pairs_hint : 0.0;
         // padded positions of the result are defined as 0 (the valid rows are scattered over this)
@@ -278,25 +279,25 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
-        qkv.m_dev = c.m_dev; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
+        qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
         if ((rc = gemm(qkv, c.dtype, s))) return rc;
         if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
-        op.m_dev = c.m_dev; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;
+        op.m_dev = c.m_dev; op.rule_table = c.rule; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;
         if ((rc = gemm(op, c.dtype, s))) return rc;
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
-        f1.m_dev = c.m_dev; f1.rows_hint = c.rows_hint; f1.concurrent = c.concurrent;
+        f1.m_dev = c.m_dev; f1.rule_table = c.rule; f1.rows_hint = c.rows_hint; f1.concurrent = c.concurrent;
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         f2.out_lo = c.XL; f2.res_hi = c.XH; f2.res_lo = c.XL; f2.ld_res = 768; f2.stats_out = c.stats;
-        f2.m_dev = c.m_dev; f2.rows_hint = c.rows_hint; f2.concurrent = c.concurrent;
+        f2.m_dev = c.m_dev; f2.rule_table = c.rule; f2.rows_hint = c.rows_hint; f2.concurrent = c.concurrent;
         if ((rc = gemm(f2, c.dtype, s))) return rc;
     }
     for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
-        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rows_hint = c.rows_hint; g.concurrent = c.concurrent; };
+        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rule_table = c.rule; g.rows_hint = c.rows_hint; g.concurrent = c.concurrent; };
         if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         vl(qkv);

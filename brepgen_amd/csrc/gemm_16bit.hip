@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
     const int G = gridDim.x;
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + BM - 1) / BM;
-    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, SPLIT, g.hybrid == 2) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
+    const int p0 = g.hybrid ? (g.rows256_dev ? *g.rows256_dev : g.rows256_host) >> 7 : 0;      // hybrid launches: the 256 x 256 kernel owns the panels below p0
     // XCD-aware tile walk (block b runs on XCD b % 8; each XCD has a private 4 MiB L2): XCD x owns the row panels x, x + 8, ...;
     // its G / 8 workgroups walk that sub-grid column-fastest, so the ~64 concurrently running tiles of an XCD share a few A row
     // panels and keep W resident.  (Column groups per XCD, a row-major walk and adjacent-column pairing of the two workgroups of a
@@ -851,10 +851,15 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         // device evaluates the rule" and "the 128 kernel alone, no rule" -- either is correct for any actual row count.
         const int rows_est = (g.m_dev != nullptr && g.rows_hint > 0) ? (int)fmin((double)g.M, g.rows_hint + 0.5) : g.M;
         const int rows_hi = p256_rows(rows_est, g.N_pad / 256, split, hmode == 2);
-        const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK);
+        // (device-side row count: the partition is read from the table compact_rows wrote -- no table entry, no hybrid launch)
+        const int ridx = p256_rule_index(g.N_pad / 256, split, hmode == 2);
+        const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK) &&
+                              (g.m_dev == nullptr || (g.rule_table != nullptr && ridx >= 0));
         if (rows_hi > 0 && can_tail) {
             GemmArgs h = g;
             h.hybrid = hmode;
+            if (g.m_dev) h.rows256_dev = g.rule_table + ridx;
+            else h.rows256_host = p256_rows(g.M, g.N_pad / 256, split, hmode == 2);
             if (split) h.p256_stagger = split_stagger(g);
             const double rows_p = fmin((double)p256_rows((int)rows_all, g.N_pad / 256, split, hmode == 2), rows_all);
             rows_tail = rows_all - rows_p;
@@ -871,6 +876,11 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     }
     GemmArgs gt = g;
     gt.hybrid = tail_only ? (g.concurrent ? 2 : 1) : 0;
+    if (tail_only) {
+        const bool split = g.out_lo != nullptr;
+        if (g.m_dev) gt.rows256_dev = g.rule_table + p256_rule_index(g.N_pad / 256, split, g.concurrent != 0);
+        else gt.rows256_host = p256_rows(g.M, g.N_pad / 256, split, g.concurrent != 0);
+    }
     const GemmArgs& g_ = gt;
     double fl_t, by_t;
     gemm_cost(g, rows_tail, fl_t, by_t);

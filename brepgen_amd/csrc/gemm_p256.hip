@@ -73,8 +73,9 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
 
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     const int nt_n = g.N_pad >> 8;
-    // (hybrid launches: only the row panels that fill complete rounds -- the 128 x 128 kernel runs the rest, bg_common.h)
-    const int T_all = (g.hybrid ? (p256_rows(Mv, nt_n, SPLIT, g.hybrid == 2) >> 8) : ((Mv + 255) >> 8)) * nt_n;
+    // (hybrid launches: only the row panels that fill complete rounds -- a 128 x 128 kernel runs the rest; the partition comes from
+    //  the host or from the table the compaction kernel wrote, bg_common.h p256_rows)
+    const int T_all = (g.hybrid ? ((g.rows256_dev ? *g.rows256_dev : g.rows256_host) >> 8) : ((Mv + 255) >> 8)) * nt_n;
     const int G = gridDim.x;
     // XCD-aware walk: workgroup b (on XCD b % 8) owns tiles first, first + G, ... of the row-major tile list, `first` being
     // consecutive for the workgroups of one XCD -- the ~32 tiles an XCD runs at a time cover 3-4 row panels x all column tiles, so

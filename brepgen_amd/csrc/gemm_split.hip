@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
     const int G = gridDim.x;
     const int Mv = g.m_dev ? *g.m_dev : g.M;                      // rows present (compacted batch: device-side count)
     if (g.m_dev) m_panels = (Mv + 127) >> 7;
-    // hybrid launches: the 256 x 256 kernel owns the row panels below p0 (bg_common.h p256_rows, evaluated identically there)
-    const int p0 = g.hybrid ? p256_rows(Mv, g.N_pad >> 8, true, g.hybrid == 2) >> 7 : 0;
+    // hybrid launches: the 256 x 256 kernel owns the row panels below p0 (bg_common.h p256_rows; both kernels read the same answer)
+    const int p0 = g.hybrid ? (g.rows256_dev ? *g.rows256_dev : g.rows256_host) >> 7 : 0;
     // XCD-aware walk (block b runs on XCD b % 8, private 4 MiB L2 each): XCD x owns row panels x, x + 8, ...; its G / 8 workgroups
     // walk that sub-grid column-fastest, so the tiles an XCD runs at a time share a few A panels and keep W resident
     const int xcd = blockIdx.x & 7, w_local = blockIdx.x >> 3, cnt = G >> 3;                  // G % 8 == 0 (launcher)

@@ -226,9 +226,9 @@ def test_gemm_partition_rule_between_the_256_and_128_kernels():
     assert f(17280, 2304, 0, 0) == 56 * 256 and f(30720, 2304, 0, 0) == (1024 // 9) * 256
     assert f(17280, 2304, 0, 1) == 68 * 256 and f(8640, 2304, 0, 1) == 34 * 256      # concurrent sample groups: >= 300 tiles -> alone
     assert f(7680, 2304, 0, 1) == 0                                           # 270 tiles: a round and a sliver -> the 128 kernel
-    # out-proj / FFN2 (3 column tiles, rounds of 255 tiles): the face-LDM batches (204 / 360 tiles) stay on the pipelined 128 x 128
-    # kernel, 720 tiles (2.8 rounds, the last one 210 tiles full) go to the 256 kernel whole, the edge nets (1626 tiles = 6 rounds
+    # out-proj / FFN2 (3 column tiles, rounds of 255 tiles): 204 tiles (the compacted face batch) fill one round well enough for the
+    # 256 kernel, 360 tiles (1.4 rounds) stay on the pipelined 128 x 128 kernel, 720 tiles (2.8 rounds, the last one 210 tiles full) go to the 256 kernel whole, the edge nets (1626 tiles = 6 rounds
     # + 96) give it its six full rounds = 510 panels
-    assert f(17280, 768, 1, 0) == 0 and f(30720, 768, 1, 0) == 0 and f(61440, 768, 1, 0) == 240 * 256
+    assert f(17280, 768, 1, 0) == 68 * 256 and f(30720, 768, 1, 0) == 0 and f(61440, 768, 1, 0) == 240 * 256
     assert f(138752, 768, 1, 0) == 510 * 256 and f(138752, 768, 1, 1) == 542 * 256 and f(40960, 768, 1, 1) == 0
     assert f(100, 768, 0, 0) == 0 and f(0, 2304, 0, 0) == 0                 # a few tiles: the 128 kernel (finer tiles fill more CUs)
