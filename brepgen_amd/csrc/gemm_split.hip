@@ -26,12 +26,14 @@
 //
 // K-steps of a tile, KT = K / 64 = 4 chunks of KT / 4 steps; chunk c serves slab c (rows 16 c .. 16 c + 15 of the wave's 64)
 // of the PREVIOUS tile:
-//   step 0 of the chunk   [A]  request the slab's residual octets + bias (6 x 16-byte loads); write the slab to the patch
-//   step 1                [B]  (loads landed: behind this step's vmcnt(0)) read the patch back, add, statistics, split, store
-//   steps 2 ..                 plain
-// Vector-memory ordering: every K-step starts with s_waitcnt vmcnt(0) (its own DMA pieces), so a load is consumed, and a store is
-// followed by a dependent load, only across a full drain -- no counted wait ever has a store between a load and its use (loads and
-// stores share vmcnt and retire out of order with respect to each other: profiles/r03/gemm_p256_split_counted_waits_WRONG.log).
+//   step 0 of the chunk   [A]  write the slab to the patch (its residual + bias were requested in the previous chunk's last step and
+//                              stay in flight across this step: the step's wait is vmcnt(6), "my DMA pieces landed")
+//   step 1                [B]  read the patch back, add, statistics, split, store -- at the START of the step, so the stores have
+//                              the whole step to be acknowledged before the next step's vmcnt(0)
+//   last step             [Z]  request the next slab's residual octets + bias (6 x 16-byte loads)
+// Vector-memory ordering: every K-step starts with a wait for its own DMA pieces; the only counted one ([A]) has nothing but older
+// loads in flight -- no counted wait ever has a store between a load and its use (loads and stores share vmcnt and retire out of
+// order with respect to each other: profiles/r03/gemm_p256_split_counted_waits_WRONG.log).
 #include "gemm16.h"
 
 namespace bg {
@@ -206,6 +208,16 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
 
     // One tile's K loop.  PEND (compile time: the workgroup's first tile has nothing pending, and a run-time test would make the
     // compiler merge the "loads consumed" and "loads in flight" states at every use): the K-steps carry the epilogue of `prev`.
+    //
+    // Roles of a chunk's K-steps (slab C of `prev`):  [A] write the slab to the patch   [B] finish it (the residual landed long ago)
+    //                                                 [Z] request the NEXT slab's residual (+ bias)
+    // Every step starts with a wait for its own DMA pieces.  That wait is vmcnt(0) except in [A]: there the only operations in flight
+    // are the previous step's 8 DMA pieces and, younger, the 6 loads of its [Z] request -- loads retire in order, so vmcnt(6) says
+    // "the DMA landed" and lets the residual travel through a second K-step.  (With vmcnt(0) everywhere the residual's miss latency
+    // -- Infinity Cache / HBM, longer than the DMA's L2 hits -- sat on the critical path of four K-steps per tile, and the pipelined
+    // kernel was exactly as fast as the serial one: profiles/r04/gemm_split_bench_first_run.log.)  A counted wait never has a store
+    // between a load and its use: [B]'s stores are drained by the vmcnt(0) of the step that follows.
+    // The tile's LAST step requests slab 0 of the tile itself (it becomes `prev`); the workgroup's last tile is served after the loop.
     auto tile_body = [&](auto pend_c) {
         constexpr bool PEND = decltype(pend_c)::value;
 #pragma unroll
@@ -215,14 +227,17 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         int kt = 0;
-        // one K-step.  ROLE 0: plain; 1: [A] of slab C; 2: [B] of slab C.  `last`: the tile's final K-step (stages the next tile)
-        auto kstep = [&](auto role_c, auto slab_c, bool last) {
-            constexpr int ROLE = PEND ? decltype(role_c)::value : 0, C = decltype(slab_c)::value;
-            wait_vmcnt<0>();                                      // my DMA pieces of this K-step landed; every older load / store done
+        // ROLE 0: plain; 1: [A]; 2: [B]; 3: [Z] (request slab C + 1).  `last`: the tile's final K-step (stages the next tile; its [Z]
+        // request is for the tile itself)
+        auto kstep = [&](auto role_c, auto slab_c, auto last_c) {
+            constexpr int C = decltype(slab_c)::value;
+            constexpr bool last = decltype(last_c)::value;
+            constexpr int ROLE = (PEND || last) ? decltype(role_c)::value : 0;
+            if (ROLE == 1) wait_vmcnt<6>(); else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my fragment (and patch) reads of the previous K-step are complete
             __builtin_amdgcn_s_barrier();
             if (ROLE == 2) {
-                // the slab's residual octets and bias were requested a K-step ago and are in their registers now; this names
+                // the slab's residual octets and bias were requested two K-steps ago and are in their registers now; this names
                 // them behind the wait above, so the compiler's own wait for them (which cannot see that wait) lands here, where
                 // nothing is in flight -- not behind the DMA issued below
                 asm volatile("" : "+v"(rb[0][0]), "+v"(rb[0][1]), "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(bs0), "+v"(bs1) :: "memory");
@@ -233,7 +248,14 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
                 a_offsets(nm0);
                 issue(slot ^ 1, a_nxt, w_nxt);
             }
-            if (ROLE == 1) slab_request(C, p_rbase, p_cbase, rb, bs0, bs1);
+            if (ROLE == 3) {
+                if (!last) {
+                    slab_request(C + 1, p_rbase, p_cbase, rb, bs0, bs1);
+                } else if (has_next) {                            // this tile becomes `prev`: its slab 0
+                    slab_request(0, m0 + wm * 64, n0 + wn * 64, rb, bs0, bs1);
+                }
+            }
+            if (ROLE == 2) slab_finish(C, p_rbase, p_cbase, rb, bs0, bs1);      // early in the step: its stores get the whole step to be acknowledged
             const unsigned char* st = lds + slot * SP_STAGE;
             V8 af[2][2], bf[2][2];
             auto load_frags = [&](int ks, int buf) {
@@ -256,17 +278,20 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ROLE == 1) slab_write(C, prev);
-            if (ROLE == 2) slab_finish(C, p_rbase, p_cbase, rb, bs0, bs1);
             __builtin_amdgcn_sched_barrier(0);
             slot ^= 1;
             ++kt;
         };
+        using R0 = std::integral_constant<int, 0>;
+        using R1 = std::integral_constant<int, 1>;
+        using R2 = std::integral_constant<int, 2>;
+        using R3 = std::integral_constant<int, 3>;
         auto chunk = [&](auto slab_c) {
             constexpr int C = decltype(slab_c)::value;
-            kstep(std::integral_constant<int, 1>{}, slab_c, false);
-            kstep(std::integral_constant<int, 2>{}, slab_c, false);
-            for (int r = 2; r + 1 < CH; ++r) kstep(std::integral_constant<int, 0>{}, slab_c, false);
-            kstep(std::integral_constant<int, 0>{}, slab_c, C == 3);
+            kstep(R1{}, slab_c, std::false_type{});
+            kstep(R2{}, slab_c, std::false_type{});
+            for (int r = 2; r + 1 < CH; ++r) kstep(R0{}, slab_c, std::false_type{});
+            kstep(R3{}, slab_c, std::integral_constant<bool, C == 3>{});
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
@@ -301,21 +326,20 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
     // ---- the last tile's epilogue has no K loop to hide in: all four slabs' residuals in flight at once, then slab by slab ----
     {
         sp_u32x4 rr[4][2][2];
-        f32x4 c0 = zero4, c1 = zero4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) slab_request(c, p_rbase, p_cbase, rr[c], c0, c1);
+        for (int c = 0; c < 4; ++c) slab_request(c, p_rbase, p_cbase, rr[c], bs0, bs1);
         slab_write(0, prev);
         wait_vmcnt<0>();                                          // before the first store: no store between a load and its use
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             asm volatile("" : "+v"(rr[c][0][0]), "+v"(rr[c][0][1]), "+v"(rr[c][1][0]), "+v"(rr[c][1][1]) :: "memory");
-        asm volatile("" : "+v"(c0), "+v"(c1) :: "memory");
+        asm volatile("" : "+v"(bs0), "+v"(bs1) :: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (c > 0) slab_write(c, prev);
             __builtin_amdgcn_wave_barrier();                      // LDS executes a wave's accesses in order: no wait needed
-            slab_finish(c, p_rbase, p_cbase, rr[c], c0, c1);
+            slab_finish(c, p_rbase, p_cbase, rr[c], bs0, bs1);
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
