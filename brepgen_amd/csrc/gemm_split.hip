@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
             int grow = rbase + c * 16 + it * 8 + r8;
             grow = grow < Mv ? grow : Mv - 1;
             const size_t o = (size_t)grow * g.ld_res + cbase + k8 * 8;
+            // (plain cache policy: non-temporal loads / stores here are -12 % for out-proj at M = 138 752 in isolation, +4-7 % at the
+            //  face-LDM sizes, +-1 % on a whole edge-net evaluation -- profiles/r04/gemm_split_bench_nt_*.log, edge_ab_nt_*.log)
             rb[it][0] = *reinterpret_cast<const sp_u32x4*>(res_hi + o);
             rb[it][1] = *reinterpret_cast<const sp_u32x4*>(res_lo + o);
         }
@@ -183,8 +185,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_split_pipe_kernel(GemmArgs g, i
                 split4_16<F16>(va4, ha, la);
                 split4_16<F16>(vb4, hb, lb);
                 const size_t o = (size_t)grow * g.ldc + cbase + k8 * 8;
-                *reinterpret_cast<uint4*>(out_hi + o) = make_uint4(ha.x, ha.y, hb.x, hb.y);
-                *reinterpret_cast<uint4*>(out_lo + o) = make_uint4(la.x, la.y, lb.x, lb.y);
+                const sp_u32x4 sh = {ha.x, ha.y, hb.x, hb.y}, sl = {la.x, la.y, lb.x, lb.y};
+                *reinterpret_cast<sp_u32x4*>(out_hi + o) = sh;
+                *reinterpret_cast<sp_u32x4*>(out_lo + o) = sl;
             }
         }
     };

@@ -92,6 +92,11 @@ for M in MS:
                 fn = lambda a=a, w=w, b=b, h=h, l=l: ops.linear_ex(a, w, b, split_out=True, res=(h, l), want_stats=True, inplace=True)
                 res[(k, vn)].append(timed(fn))
     print(f"M = {M}")
+    for k, (a, w, b, h, l, K) in cases.items():      # the same product WITHOUT the residual: 16-bit output, K loop + a light epilogue
+        for vn, kv in (("128", {10: 2}), ("256+128", {10: 0})):
+            setv(kv)
+            us = statistics.median(timed(lambda: ops.linear(a, w, b, out_dtype=dt)) for _ in range(R))
+            print(f"  {k:8s} plain 16-bit output, {vn:8s} {us:7.1f} us {2.0 * M * 768 * K / us / 1e6:5.0f} TF")
     for k, (a, w, b, h, l, K) in cases.items():
         by = 2.0 * M * K + 2.0 * 768 * K + 8.0 * M * 768 + 8.0 * M * 12 + 4 * 768
         print(f"  {k:8s} ({by / 1e6:6.1f} MB algorithmic)")
