@@ -19,8 +19,10 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 W = max(int(sys.argv[3]) if len(sys.argv) > 3 else 3, 3)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 inst = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc*", "pmc_counter_collection.csv"))):
+for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "pmc[0-9]", "pmc_counter_collection.csv"))):
     for r in csv.DictReader(open(path)):
+        if r["Counter_Name"].startswith("SQ_"):                   # the SQ pass runs on a shorter, differently mixed run: tools/pmc_dirs.py
+            continue
         name = r["Kernel_Name"]
         if "bg::" not in name:
             continue
