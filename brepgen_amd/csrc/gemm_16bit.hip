@@ -328,11 +328,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
 //   P_FOLD16   same with the LayerNorm fold (stats_in / colsum)         -- QKV / FFN1 of the denoisers
 //   P_GENERAL  fp32 or 16-bit output with fp32 addends (add / add2)     -- fp32 residual stream, embeds, VAE residuals
 //   P_SPLIT    split (hi, lo) output, addend = split residual or fp32 broadcast rows, optional row statistics
-//                                                                       -- out-proj / FFN2 / token embeds of the denoisers
+//                                                                       -- token embeds of the denoisers (row maps, broadcast addends);
+//                                                                          out-proj / FFN2 only as the tests' baseline: the product
+//                                                                          path runs them on gemm_split.hip / gemm_p256.hip
 
-// CONV: the A operand is gathered from a conv window (implicit GEMM).  PURE (P_SPLIT only): the residual-stream form of the denoiser
-// layers -- split residual in, (hi, lo) + row statistics out, no activation, no broadcast addends, no row map -- with the
-// epilogue's run-time option checks folded away (same arithmetic, fewer instructions on the epilogue's latency chain).
+// CONV: the A operand is gathered from a conv window (implicit GEMM).  PURE (with CONV): the convolution as the VAE passes issue it --
+// fp32 output, fp32 residual of the same shape or none, no activation, no second addend -- with the epilogue's run-time option checks
+// folded away (same arithmetic, 904 -> 242 VALU instructions per tile epilogue).
 template <bool F16, int MODE, bool CONV = false, bool PURE = false>
 __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, int m_panels) {
     constexpr bool FAST = MODE == P_PLAIN16 || MODE == P_FOLD16, FOLD = MODE == P_FOLD16, SPLIT = MODE == P_SPLIT;
