@@ -353,7 +353,8 @@ def pmc_traffic(kernel, launches_per_step):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            row = json.load(f).get(kernel.split("(")[0], {})
+            table = json.load(f)
+            row = table.get(kernel) or table.get(kernel.split("(")[0], {})
     except (OSError, ValueError):
         return None, None
     lps = row.get("launches_per_step")

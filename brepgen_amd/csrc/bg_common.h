@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);

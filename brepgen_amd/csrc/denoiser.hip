@@ -36,7 +36,7 @@ int g_cap = 0, g_n = 0;
 bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(generic: 128x64 / 64x64 tiles)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
                                           "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
-                                          "gemm16_split_pipe_kernel(128x128)"};
+                                          "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {

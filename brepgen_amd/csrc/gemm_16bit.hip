@@ -840,7 +840,7 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         const bool split = g.out_lo != nullptr;
         if (g_tune[TUNE_P256_MODE] == 1) {
             gemm_cost(g, rows_all, fl, by);
-            ProfScope prof(PK_GEMM_P256, fl, by, s);
+            ProfScope prof(split ? PK_GEMM_P256_SPLIT : PK_GEMM_P256, fl, by, s);     // (booked apart: HBM-bound vs MFMA-bound launches)
             GemmArgs h = g;
             if (split) h.p256_stagger = split_stagger(g);
             return launch_p256<F16>(h, s);
@@ -868,7 +868,7 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
             gemm_cost(g, rows_p, fl, by);
             int rc;
             {
-                ProfScope prof(PK_GEMM_P256, fl, by, s);
+                ProfScope prof(split ? PK_GEMM_P256_SPLIT : PK_GEMM_P256, fl, by, s);
                 rc = launch_p256<F16>(h, s);
             }
             if (rc) return rc;
