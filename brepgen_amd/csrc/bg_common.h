@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -35,8 +35,8 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
-//  15: small-launch threshold -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
+//  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 15: small-launch threshold -- each backs a bit-equality test, see gemm_16bit.hip launch16)
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -267,6 +267,12 @@ int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, co
 // keys; key_pad is ignored); otherwise sample b owns rows b*N .. b*N+N-1 and key_pad marks the padded keys.
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
               const int* offsets = nullptr, double pairs_hint = 0.0, double rows_hint = 0.0);
+// QKV (LayerNorm fold) + attention of short, equally long, unmasked sequences in one launch (qkv_attn.hip)
+bool qkv_attn_eligible(int B, int N, int dtype, const void* stats_in, const void* colsum, const void* bias);
+bool qkv_attn_worthwhile(int B, int N);      // enough (sample group, head) tiles to fill the chip
+int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
+                  int B, int N, int dtype, float ln_eps, hipStream_t s);
+
 // valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
 // covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),
 // src_row [B * n_mask * rep]: padded-layout index of every compact row, in order.

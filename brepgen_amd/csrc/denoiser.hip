@@ -36,7 +36,8 @@ int g_cap = 0, g_n = 0;
 bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(generic: 128x64 / 64x64 tiles)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
                                           "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
-                                          "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)"};
+                                          "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)",
+                                          "qkv_attn_kernel(256x192 + attention)"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {
@@ -274,14 +275,22 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
 
     // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
+    const bool fused_qkv = c.fold && !varlen && key_pad == nullptr && g_tune[TUNE_QKV_ATTN] != 1 &&
+                           qkv_attn_eligible(B, N, c.dtype, c.stats, w->layers[0].qkv_colsum, w->layers[0].b_qkv) &&
+                           qkv_attn_worthwhile(B, N);
     for (int li = 0; c.fold && li < w->n_layer; ++li) {
         // x = XH + XL.  LN1 / LN2 are folded: QKV and FFN1 read the raw 16-bit rows XH and normalise in their epilogue.
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
         qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
-        if ((rc = gemm(qkv, c.dtype, s))) return rc;
-        if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
+        if (fused_qkv) {
+            // short, equally long, unmasked sequences (SurfPosNet): q|k|v never leave the CU (qkv_attn.hip; bit-identical)
+            if ((rc = qkv_attention(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, B, N, c.dtype, 1e-5f, s))) return rc;
+        } else {
+            if ((rc = gemm(qkv, c.dtype, s))) return rc;
+            if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;
+        }
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
         op.m_dev = c.m_dev; op.rule_table = c.rule; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;

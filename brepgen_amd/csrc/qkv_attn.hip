@@ -1,0 +1,457 @@
+// QKV projection (LayerNorm folded) + multi-head self-attention of one encoder layer in ONE launch, for batches of short,
+// equally long sequences without a key-padding mask (the face LDM's SurfPosNet: 30 / 60 tokens per sample, network.py:1076-1078 ->
+// torch/nn/modules/transformer.py + MultiheadAttention):
+//
+//   q|k|v[m, :] = T(rstd_m * (x_m . W'^T) - mean_m rstd_m colsum + b')        (the P_FOLD16 epilogue of gemm_p256.hip)
+//   out[b, :, head] = softmax(q k^T) v  per sample b and head                  (attn16_kernel, attn.hip; 1/8 folded into W'_q)
+//
+// As two launches the 256 x 256 GEMM writes q|k|v (4.6 KB per token) and the attention kernel reads it back: 283 MB per layer at
+// the face LDM's 30 720 tokens, all of it inside the GEMM's store burst (every CU reaches its epilogue at the same time) and the
+// attention kernel's read -- neither overlaps MFMA work.  Here q|k|v of one (sample group, head) never leave the CU.
+//
+// Tile = 256 token slots x 192 columns (q, k, v of ONE head, 64 each) x K-steps of 64; the 256 slots are 256 / S samples of S = 64
+// (or 32) slots each, a sample's N <= S tokens followed by copies of its last token (never stored, masked as keys) -- so the rows
+// of a tile are whole samples and a wave's 32 queries belong to one of them.  8 waves as 4 (rows) x 2 (columns), 64 x 96 per wave
+// = 2 x 3 MFMA tiles, transposed product (weights as the A operand: a lane owns one token).  LDS: two K-step buffers of 56 KiB
+// (A rows 0-127 | A rows 128-255 | W rows q, k, v) + 48 KiB for the epilogue operands; one workgroup per CU.
+//
+// K loop: the phase discipline of gemm_p256.hip on this geometry -- waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one
+// wave is in an 8-MFMA segment while the other reads fragments and issues LDS-DMA.  Six phases per iteration (two K-steps), phase =
+// [reads + DMA] barrier [8 MFMAs: both row tiles x 4 k-slices of one column tile] barrier:
+//   p   reads (buffer)            LDS-DMA issued per wave              wait         MFMAs
+//   1   W j0, A          (0)      buffer 1, W (t+1): 3 pieces                       column tile 0
+//   2   W j1, W j2       (0)                                                        column tile 1
+//   3   --                        buffer 0, A (t+2): 4 pieces          vmcnt(4)     column tile 2     -> buffer 1 (t+1) landed
+//   4   W j0, A          (1)      buffer 0, W (t+2): 3 pieces                       column tile 0
+//   5   W j1, W j2       (1)                                                        column tile 1
+//   6   --                        buffer 1, A (t+3): 4 pieces          vmcnt(4)     column tile 2     -> buffer 0 (t+2) landed
+// Write-after-read: a region last read in phase R (by any wave, the late group included) is re-staged from phase R + 2 on -- A is
+// last read in phases 1 / 4, W in 2 / 5.  Read-after-write: the counted wait sits before the first barrier of phases 3 / 6, the
+// first read of that buffer one phase later (gemm_p256.hip: the same argument).
+//
+// Epilogue (all eight waves together): LayerNorm-fold coefficients of the lane's two tokens from the staged statistics partials,
+// fold + bias + 16-bit rounding exactly as P_FOLD16, then q, k (row-major, the attention kernel's swizzled K-tile layout) and v
+// (transposed per sample, that kernel's V^T layout) go to the LDS the ring occupied; one barrier; every wave runs the attention
+// of 32 queries of one sample -- attn16_kernel's arithmetic, instruction for instruction -- and stores 32 x 64 outputs.
+// Results are bit-identical to gemm (P_FOLD16) + attention (tests/test_gpu_round4.py).
+#include "gemm16.h"
+#include <math.h>
+
+namespace bg {
+
+constexpr int QA_BUF = 57344, QA_AHALF = 16384, QA_WOFF = 32768, QA_RING = 2 * QA_BUF;      // 2 x 56 KiB
+constexpr int QA_AUX = QA_RING, QA_BIAS = 24576, QA_CSUM = 25600;                          // aux: [0, 24K) statistics, bias, column sums
+constexpr int QA_QIMG = 0, QA_KIMG = 32768, QA_VIMG = 65536;                               // epilogue images (alias the ring)
+constexpr int QA_LDS = 163840;
+
+struct QkvAttnArgs {
+    const void* a;            // [M, 768] raw 16-bit residual rows (hi plane)
+    const void* w;            // [2304, 768] = T(gamma * W_qkv), q rows pre-scaled by 1/8
+    const float* bias;        // [2304] b + W beta
+    const float* colsum;      // [2304]
+    const float* stats_in;    // [12][M][2] (sum, sum of squares) per 64-column part
+    void* out;                // [M, 768] attention output (16-bit)
+    void* dbg;                // optional [M, 2304]: the q|k|v a two-launch run would have written (tests)
+    int B, N, M;
+    float ln_eps;
+};
+
+__device__ __forceinline__ int qa_opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+template <bool F16, int S, bool DBG = false>
+__global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
+    using E = Elem<F16>;
+    using T = typename E::T;
+    using V8 = typename E::V8;
+    using V4 = typename E::V4;
+    constexpr int SPT = 256 / S;              // samples per tile
+    constexpr int WPS = S / 32;               // waves (query blocks) per sample
+    constexpr int VS = S + 4;                 // V^T row stride in elements (68 / 36: odd multiples of 8 bytes -> conflict-free ds_read_b64)
+    constexpr int LD = BG_D_MODEL;            // 768
+    __shared__ __attribute__((aligned(16))) unsigned char lds[QA_LDS];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int late = wave >> 2;               // waves 4-7 run one barrier behind
+    const int n_groups = (g.B + SPT - 1) / SPT;
+    const int T_all = n_groups * BG_N_HEAD;
+    const int G = gridDim.x;
+    int L = xcd_remap(blockIdx.x, G);
+    if (L >= T_all) return;
+
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.a);
+    const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.w);
+    constexpr unsigned lda_b = LD * 2u, ldw_b = LD * 2u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds);
+    const unsigned aux_lds = lds0 + QA_AUX;
+    const unsigned char* aux = lds + QA_AUX;
+
+    auto dma = [&](unsigned dst, const unsigned char* src, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+    auto lds_done_bar = [&]() {               // every LDS access of every wave issued so far is complete
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+    };
+
+    // ---- LDS-DMA pieces (1 KiB = 8 rows x 128 B): wave w moves pieces w, w + 8 of each A half and piece w of each of W's q, k, v ----
+    unsigned ha[2][2], hw;
+    auto piece_row = [&](int ln, int r) { return (wave + 8 * r) * 8 + (ln >> 3); };
+    auto piece_chunk = [&](int ln, int r) { return (unsigned)(((ln & 7) ^ ((piece_row(ln, r) >> 1) & 7)) * 16); };
+    auto slot_row = [&](int grp, int tile_row) {                  // global token of a tile row (slots past a sample's end: its last token)
+        int smp = grp * SPT + tile_row / S;
+        smp = smp < g.B ? smp : g.B - 1;
+        int tok = tile_row % S;
+        tok = tok < g.N ? tok : g.N - 1;
+        return smp * g.N + tok;
+    };
+    auto a_offsets = [&](int grp) {
+        const int ln = qa_opaque(threadIdx.x & 63);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                ha[hh][r] = (unsigned)slot_row(grp, hh * 128 + piece_row(ln, r)) * lda_b + piece_chunk(ln, r);
+    };
+    {
+        const int ln = threadIdx.x & 63;
+        hw = (unsigned)piece_row(ln, 0) * ldw_b + piece_chunk(ln, 0);
+    }
+    auto stage_a = [&](int buf, const unsigned char* src) {      // src = A + byte offset of the K-step
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                dma(lds0 + (unsigned)(buf * QA_BUF + hh * QA_AHALF + (wave + 8 * r) * 1024), src, ha[hh][r]);
+    };
+    auto stage_w = [&](int buf, const unsigned char* src) {      // src = W + head rows + byte offset of the K-step
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3)
+            dma(lds0 + (unsigned)(buf * QA_BUF + QA_WOFF + (wave + 8 * c3) * 1024), src + (size_t)c3 * LD * ldw_b, hw);
+    };
+    // epilogue operands: statistics partials of the tile's 256 token slots ([row half][part][128 x (sum, sumsq)], 3 pieces per wave),
+    // bias and column sums of the head's 192 columns (waves 0 / 1)
+    auto stage_aux = [&](int grp, int head) {
+        const int ln = qa_opaque(threadIdx.x & 63);
+        const int gh = wave >> 2;
+        int row = slot_row(grp, gh * 128 + 2 * ln);
+        row = (row & 1) ? row - 1 : row;                          // (N even: a slot pair never straddles samples; past the end: the last pair)
+        const unsigned char* sb = reinterpret_cast<const unsigned char*>(g.stats_in);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int part = (wave & 3) * 3 + r;
+            dma(aux_lds + (unsigned)(gh * 12288 + part * 1024), sb + (size_t)part * (size_t)g.M * 8, (unsigned)(row >> 1) * 16u);
+        }
+        int c3 = ln >> 4;
+        c3 = c3 < 3 ? c3 : 2;
+        const unsigned voff = (unsigned)(c3 * LD + (ln & 15) * 4) * 4u;
+        if (wave == 0) dma(aux_lds + QA_BIAS, reinterpret_cast<const unsigned char*>(g.bias + head * 64), voff);
+        if (wave == 1) dma(aux_lds + QA_CSUM, reinterpret_cast<const unsigned char*>(g.colsum + head * 64), voff);
+    };
+
+    // ---- fragment reads ----
+    unsigned a_rd, b_rd, xk[4];
+    {
+        const int ln = threadIdx.x & 63, l31 = ln & 31, hq = ln >> 5, sw = (l31 >> 1) & 7;
+        a_rd = (unsigned)(wm * 64 + l31) * 128u;                  // + i * 4096
+        b_rd = (unsigned)QA_WOFF + (unsigned)(wn * 96 + l31) * 128u;   // + j * 4096
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xk[ks] = (unsigned)(((ks * 2 + hq) ^ sw) << 4);
+    }
+    f32x16 acc[2][3];
+    V8 fa[2][4], fb[3][4];
+    auto read_a = [&](const unsigned char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[i][ks] = *reinterpret_cast<const V8*>(st + a_rd + i * 4096 + xk[ks]);
+    };
+    auto read_b = [&](const unsigned char* st, int j) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[j][ks] = *reinterpret_cast<const V8*>(st + b_rd + j * 4096 + xk[ks]);
+    };
+    auto segment = [&](int j) {                                  // 8 MFMAs: both row tiles x column tile j
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j] = E::mfma(fb[j][ks], fa[i][ks], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    constexpr int KT = LD / G_BK;                                 // 12 K-steps
+    const unsigned char* b0 = lds;
+    const unsigned char* b1 = lds + QA_BUF;
+
+    int grp = L / BG_N_HEAD, head = L % BG_N_HEAD;
+    stage_aux(grp, head);
+    for (;;) {
+        const unsigned char* w_cur = Wb + (size_t)head * 64 * ldw_b;
+        a_offsets(grp);
+        // ---- prologue: buffer 0 complete, A of buffer 1 in flight (as if issued in phase 6) ----
+        stage_a(0, Ab); stage_w(0, w_cur); stage_a(1, Ab + 2 * G_BK);
+        wait_vmcnt<4>();
+        bar();
+        if (late) bar();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // one iteration = K-steps t (buffer 0), t + 1 (buffer 1); kb = byte offset of K-step t inside a row
+        auto iteration = [&](unsigned kb, bool more) {
+            // phase 1
+            read_b(b0, 0); __builtin_amdgcn_sched_barrier(0); read_a(b0);
+            stage_w(1, w_cur + kb + 2 * G_BK);
+            bar(); segment(0); bar();
+            // phase 2
+            read_b(b0, 1); read_b(b0, 2);
+            bar(); segment(1); bar();
+            // phase 3
+            if (more) { stage_a(0, Ab + kb + 4 * G_BK); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+            bar(); segment(2); bar();
+            // phase 4
+            read_b(b1, 0); __builtin_amdgcn_sched_barrier(0); read_a(b1);
+            if (more) stage_w(0, w_cur + kb + 4 * G_BK);
+            bar(); segment(0); bar();
+            // phase 5
+            read_b(b1, 1); read_b(b1, 2);
+            bar(); segment(1); bar();
+            // phase 6
+            if (more) { stage_a(1, Ab + kb + 6 * G_BK); wait_vmcnt<4>(); }
+            bar(); segment(2); bar();
+        };
+        for (int t = 0; t + 2 < KT; t += 2) iteration((unsigned)t * (2 * G_BK), true);
+        iteration((unsigned)(KT - 2) * (2 * G_BK), false);
+        if (!late) bar();                                         // both wave groups enter the epilogue together
+
+        // ---------------- epilogue ----------------
+        const int ln = qa_opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
+        float2 cf[2];
+        {
+            const unsigned char* sg = aux + (wm >> 1) * 12288;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rg = (wm & 1) * 64 + i * 32 + l31;
+                float ps[16], pq[16];
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) {
+                    const float2 v = pp < FOLD_PARTS ? reinterpret_cast<const float2*>(sg + pp * 1024)[rg] : make_float2(0.f, 0.f);
+                    ps[pp] = v.x; pq[pp] = v.y;
+                }
+                cf[i] = ln_fold_coeffs(tree16(ps), tree16(pq), LD, g.ln_eps);
+                asm volatile("" : "+v"(cf[i].x), "+v"(cf[i].y) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        T* dbg = reinterpret_cast<T*>(g.dbg);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tc0 = wn * 96 + j * 32;                     // wave-uniform: first tile column of this column tile
+            const int c3 = tc0 >> 6, d0 = tc0 & 63;               // q / k / v, first head dimension
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = d0 + 8 * q + 4 * hq;
+                const float4 bz = *reinterpret_cast<const float4*>(aux + QA_BIAS + (unsigned)(c3 * 64 + d) * 4u);
+                const float4 cs = *reinterpret_cast<const float4*>(aux + QA_CSUM + (unsigned)(c3 * 64 + d) * 4u);
+                const float b4[4] = {bz.x, bz.y, bz.z, bz.w}, c4[4] = {cs.x, cs.y, cs.z, cs.w};
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ln_fold_apply(acc[i][j][4 * q + e], cf[i].x, cf[i].y, c4[e], b4[e]);
+                    // (fp16: hipcc would fuse the outer fma with the conversion -- v_fma_mixlo_f16 rounds ONCE, the other kernels
+                    //  round to fp32 and then to fp16; the fp32 value is pinned so that the two launches and this one agree bit for bit)
+                    if (F16) asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+                    union { V4 v; uint2 u; T t[4]; } pk;
+                    pk.v = E::pack4(v[0], v[1], v[2], v[3]);
+                    const int R = wm * 64 + i * 32 + l31;         // token slot of the tile
+                    if (c3 < 2) {
+                        *reinterpret_cast<uint2*>(lds + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
+                    } else {
+                        T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + (R / S) * (64 * VS) + (R % S);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vt[(d + e) * VS] = pk.t[e];
+                    }
+                    if (DBG) {
+                        const int smp = grp * SPT + R / S, tok = R % S;
+                        if (smp < g.B && tok < g.N)
+                            *reinterpret_cast<uint2*>(dbg + (size_t)(smp * g.N + tok) * (3 * LD) + c3 * LD + head * 64 + d) = pk.u;
+                    }
+                }
+            }
+        }
+        lds_done_bar();                                           // images complete; nobody reads the aux region any more
+
+        // the next tile of this workgroup: its epilogue operands travel while this tile's attention runs
+        const int Ln = L + G;
+        const bool has_next = Ln < T_all;
+        const int grp_n = Ln / BG_N_HEAD, head_n = Ln % BG_N_HEAD;
+        if (has_next) stage_aux(grp_n, head_n);
+
+        // ---- attention: 32 queries of one sample per wave (attn16_kernel, attn.hip) ----
+        {
+            const int slot = wave / WPS, qb = wave % WPS;
+            const int smp = grp * SPT + slot;
+            if (smp < g.B) {
+                const int h = hq;
+                const unsigned char* qimg = lds + QA_QIMG + (slot * S + qb * 32) * 128;
+                const unsigned char* ktile = lds + QA_KIMG + slot * S * 128;
+                const T* vt = reinterpret_cast<const T*>(lds + QA_VIMG) + slot * (64 * VS);
+                const int sw = (l31 >> 1) & 7;
+                V8 qf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const V8*>(qimg + l31 * 128 + (((ks * 2 + h) ^ sw) << 4));
+                f32x16 o[2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+                float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < WPS; ++sub) {
+                    if (sub * 32 >= g.N) break;                   // uniform: sub-tile entirely past the last key
+                    f32x16 s;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const V8 kf = *reinterpret_cast<const V8*>(ktile + (sub * 32 + l31) * 128 + (((ks * 2 + h) ^ sw) << 4));
+                        s = E::mfma(kf, qf[ks], s);
+                    }
+                    // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query l31
+                    float mloc = -INFINITY;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = sub * 32 + 8 * g4 + 4 * h + e;
+                            s[4 * g4 + e] += key >= g.N ? -INFINITY : 0.f;
+                        }
+                        mloc = fmaxf(mloc, fmaxf(fmaxf(s[4 * g4 + 0], s[4 * g4 + 1]), fmaxf(s[4 * g4 + 2], s[4 * g4 + 3])));
+                    }
+                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                    const float m_new = fmaxf(m_run, mloc);
+                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                    const float alpha = __expf(m_run - m_use);
+                    float psum = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[r] = __expf(s[r] - m_use);
+                        psum += s[r];
+                    }
+                    l_run = l_run * alpha + psum;
+                    m_run = m_new;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        V8 pb;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pb[e] = (T)s[8 * sl + e];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const T* vrow = vt + (dt * 32 + l31) * VS + sub * 32 + 16 * sl + 4 * h;
+                            const V4 lo = *reinterpret_cast<const V4*>(vrow);
+                            const V4 hi = *reinterpret_cast<const V4*>(vrow + 8);
+                            V8 va;
+                            va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                            va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                            o[dt] = E::mfma(va, pb, o[dt]);
+                        }
+                    }
+                }
+                const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+                const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+                const int qi = qb * 32 + l31;
+                if (qi < g.N) {
+                    T* op = reinterpret_cast<T*>(g.out) + (size_t)(smp * g.N + qi) * LD + head * 64;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int d = dt * 32 + 8 * g4 + 4 * h;
+                            V4 pk;
+                            pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
+                            pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
+                            *reinterpret_cast<V4*>(op + d) = pk;
+                        }
+                }
+            }
+        }
+        if (!has_next) break;
+        lds_done_bar();                                           // the images are consumed: the ring may be re-staged
+        L = Ln; grp = grp_n; head = head_n;
+    }
+}
+
+// uniform short sequences, no key mask, LayerNorm fold operands present
+bool qkv_attn_eligible(int B, int N, int dtype, const void* stats_in, const void* colsum, const void* bias) {
+    return (dtype == BG_BF16 || dtype == BG_F16) && B > 0 && N >= 2 && N <= 64 && (N & 1) == 0 && stats_in && colsum && bias &&
+           (((size_t)stats_in) & 15) == 0 && (size_t)B * N * BG_D_MODEL * 2 < 0xffffffffull;
+}
+
+// One 256-slot tile per CU and round: below a round and a half of tiles the two-launch path (finer tiles) is the better fit.
+bool qkv_attn_worthwhile(int B, int N) {
+    const int spt = N <= 32 ? 8 : 4;
+    return (B + spt - 1) / spt * BG_N_HEAD >= 384;
+}
+
+int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
+    const int S = g.N <= 32 ? 32 : 64, spt = 256 / S;
+    const int tiles = (g.B + spt - 1) / spt * BG_N_HEAD;
+    if (tiles <= 0) return 0;
+    const double rows = (double)g.B * g.N;
+    ProfScope prof(PK_QKV_ATTN, 2.0 * rows * BG_D_MODEL * 3 * BG_D_MODEL + 4.0 * BG_N_HEAD * (double)g.B * g.N * g.N * BG_D_HEAD,
+                   rows * (2.0 * BG_D_MODEL * 2 + FOLD_PARTS * 8.0) + 2.0 * 3 * BG_D_MODEL * BG_D_MODEL + 2 * 4.0 * 3 * BG_D_MODEL, s);
+    const int grid = tiles < 256 ? tiles : 256;
+    const bool f16 = dtype == BG_F16;
+#define QA_LAUNCH(F, SS, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, D>), dim3(grid), dim3(512), 0, s, g)
+    if (g.dbg) {                                                   // (tests: the q|k|v image is written out as well)
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, true); else QA_LAUNCH(false, 64, true); }
+        else { if (f16) QA_LAUNCH(true, 32, true); else QA_LAUNCH(false, 32, true); }
+    } else {
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, false); else QA_LAUNCH(false, 64, false); }
+        else { if (f16) QA_LAUNCH(true, 32, false); else QA_LAUNCH(false, 32, false); }
+    }
+#undef QA_LAUNCH
+    return launch_status("qkv_attn");
+}
+
+int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
+                  int B, int N, int dtype, float ln_eps, hipStream_t s) {
+    const QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, nullptr, B, N, B * N, ln_eps};
+    return qkv_attention_launch(g, dtype, s);
+}
+
+}  // namespace bg
+
+extern "C" int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
+                               void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream) {
+    BG_REQUIRE(x_hi && w_qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_qkv_attn_fwd: null pointer or negative size");
+    BG_REQUIRE(bg::qkv_attn_eligible(B, N, dtype, stats_in, colsum, bias), BG_E_SHAPE,
+               "bg_qkv_attn_fwd: needs 16-bit operands, an even N in [2, 64], LayerNorm-fold statistics / column sums / bias (16-byte aligned)");
+    BG_REQUIRE(((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
+               ((uintptr_t)bias & 15) == 0 && ((uintptr_t)colsum & 15) == 0, BG_E_ALIGN, "bg_qkv_attn_fwd: 16-byte alignment");
+    bg::QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, B, N, B * N, ln_eps};
+    return bg::qkv_attention_launch(g, dtype, (hipStream_t)stream);
+}

@@ -37,11 +37,11 @@ def _record(key, value):
 @pytest.fixture
 def tune():
     """bg_tune_set with automatic reset of the keys this file touches (8: phase-group delay, 10: 256-kernel mode, 12: split-kernel
-    choice, 15: small-launch threshold)."""
+    choice, 13: fused QKV + attention, 15: small-launch threshold)."""
     from brepgen_amd import _lib
     lib = _lib.load()
     yield lib.bg_tune_set
-    for k in (8, 10, 12, 15):
+    for k in (8, 10, 12, 13, 15):
         lib.bg_tune_set(k, 0)
 
 
@@ -179,3 +179,62 @@ def test_p256_split_phase_groups_are_bit_identical(pc, tune):
             outs.append((r["out"].clone(), r["lo"].clone(), r["stats"].clone()))
         for o in outs[1:]:
             assert all(torch.equal(x, y) for x, y in zip(outs[0], o)), K
+
+
+# ---- QKV + attention in one launch (csrc/qkv_attn.hip) ------------------------------------------------------------------
+def _qkv_case(B, N, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    M = B * N
+    x = rn(M, 768) * 2
+    grp = x.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().cuda()
+    w = rn(2304, 768) * 0.04
+    w[:768] *= 0.125                                              # (the weight packer folds 1 / sqrt(d_head) into the q rows)
+    w = w.to(dt).cuda()
+    return x.to(dt).cuda(), w, rn(2304).cuda(), w.float().sum(1).contiguous(), stats
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,N", [(4, 60), (7, 60), (131, 60), (512, 60), (8, 30), (13, 30), (512, 30), (5, 64), (9, 32), (6, 2), (6, 34), (300, 48)])
+def test_fused_qkv_attention_is_bit_identical_to_the_two_launches(pc, dt, B, N):
+    """LayerNorm-fold QKV GEMM + attention as ONE launch (the face LDM's SurfPosNet: 30 / 60 tokens, no mask) against
+    bg_gemm_ex_fwd + bg_attn_fwd: the q|k|v image the fused kernel keeps in LDS and the attention output, bit for bit -- partial
+    last sample groups (B not a multiple of 4 / 8), every slot count (N = 2 .. 64, both slot sizes), several tiles per workgroup
+    (B = 512: 6 rounds).  Repeated: a race between the ring and the epilogue images would not necessarily show the first time."""
+    import hip_ops as ops
+    a, w, b, cs, stats = _qkv_case(B, N, dt, B * 100 + N)
+    qkv = ops.linear_ex(a, w, b, stats_in=stats, colsum=cs)["out"]
+    ref = ops.attention(qkv, None, B, N)
+    for _ in range(3):
+        out, img = ops.qkv_attention(a, w, b, cs, stats, B, N, want_qkv=True)
+        out2 = ops.qkv_attention(a, w, b, cs, stats, B, N)
+        torch.cuda.synchronize()
+        assert torch.equal(img, qkv), (B, N, int((img.float() != qkv.float()).sum()))
+        assert torch.equal(out, ref) and torch.equal(out2, ref), (B, N, int((out.float() != ref.float()).sum()))
+    assert torch.isfinite(ref.float()).all()
+
+
+def test_fused_qkv_attention_rejects_what_it_does_not_cover(pc):
+    import hip_ops as ops
+    a, w, b, cs, stats = _qkv_case(4, 33, BF16, 1)                 # odd N: the statistics travel two rows per element
+    with pytest.raises(RuntimeError):
+        ops.qkv_attention(a, w, b, cs, stats, 4, 33)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,S,n_split", [(512, 60, 1), (512, 60, 2), (512, 30, 1), (300, 60, 2)])
+def test_fused_qkv_attention_inside_the_denoiser(pc, tune, dt, B, S, n_split):
+    """SurfPosNet at the face LDM's shapes: eps with the fused launch == eps with GEMM + attention (key 13 = 1), bit for bit,
+    one and two sample groups in flight."""
+    m, _ = pc.build_net("SurfPosNet", 11, False, dt)
+    m.n_split = n_split
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfPosNet", B, S, 1, False)]
+    with torch.no_grad():
+        tune(13, 1)
+        ref = m(*args).clone()
+        tune(13, 0)
+        for _ in range(2):
+            got = m(*args)
+            torch.cuda.synchronize()
+            assert torch.isfinite(ref).all() and torch.equal(ref, got), (B, S, n_split)
