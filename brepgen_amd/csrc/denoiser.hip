@@ -277,7 +277,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
     const bool fused_qkv = c.fold && !varlen && key_pad == nullptr && g_tune[TUNE_QKV_ATTN] != 1 &&
                            qkv_attn_eligible(B, N, c.dtype, c.stats, w->layers[0].qkv_colsum, w->layers[0].b_qkv) &&
-                           qkv_attn_worthwhile(B, N);
+                           (g_tune[TUNE_QKV_ATTN] == 2 || qkv_attn_worthwhile(B, N));
     for (int li = 0; c.fold && li < w->n_layer; ++li) {
         // x = XH + XL.  LN1 / LN2 are folded: QKV and FFN1 read the raw 16-bit rows XH and normalise in their epilogue.
         const bg_layer_weights& L = w->layers[li];
