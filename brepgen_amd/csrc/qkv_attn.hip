@@ -40,9 +40,12 @@
 namespace bg {
 
 constexpr int QA_BUF = 57344, QA_AHALF = 16384, QA_WOFF = 32768, QA_RING = 2 * QA_BUF;      // 2 x 56 KiB
-constexpr int QA_AUX = QA_RING, QA_BIAS = 24576, QA_CSUM = 25600;                          // aux: [0, 24K) statistics, bias, column sums
-constexpr int QA_QIMG = 0, QA_KIMG = 32768, QA_VIMG = 65536;                               // epilogue images (alias the ring)
 constexpr int QA_LDS = 163840;
+constexpr int QA_AUX = QA_RING, QA_BIAS = QA_LDS - QA_AUX - 2048, QA_CSUM = QA_BIAS + 1024; // aux: [0, 24K) statistics ... bias, column sums at the end
+// epilogue images: buffer 1 and the statistics' place (consumed inside the K loop) -- buffer 0 already holds K-step 0 of the next tile
+constexpr int QA_QIMG = QA_BUF, QA_KIMG = QA_QIMG + 32768, QA_VIMG = QA_KIMG + 32768;
+
+static_assert(QA_VIMG + 8 * 64 * 36 * 2 <= QA_AUX + QA_BIAS && QA_VIMG + 4 * 64 * 68 * 2 <= QA_AUX + QA_BIAS, "the V^T image ends below the bias / column sums");
 
 struct QkvAttnArgs {
     const void* a;            // [M, 768] raw 16-bit residual rows (hi plane)
@@ -61,7 +64,7 @@ __device__ __forceinline__ int qa_opaque(int x) {
     return x;
 }
 
-template <bool F16, int S, bool DBG = false>
+template <bool F16, int S, int DBG = 0>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     using E = Elem<F16>;
     using T = typename E::T;
@@ -74,8 +77,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[QA_LDS];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int late = wave >> 2;               // waves 4-7 run one barrier behind
+    // (wm, wn): rows 64 wm .., columns 96 wn ..; waves w and w + 4 share a SIMD: one of them gets wn = 0 (q + half of k: 24 wide LDS
+    // stores in the epilogue), the other wn = 1 (half of k + v: the transposing 16-bit stores)
+    const int wm = wave >> 1, wn = (wave ^ (wave >> 2)) & 1;
+    const int late = wave >> 2;               // waves 4-7 (rows 128-255) run one barrier behind
     const int n_groups = (g.B + SPT - 1) / SPT;
     const int T_all = n_groups * BG_N_HEAD;
     const int G = gridDim.x;
@@ -141,9 +146,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         for (int c3 = 0; c3 < 3; ++c3)
             dma(lds0 + (unsigned)(buf * QA_BUF + QA_WOFF + (wave + 8 * c3) * 1024), src + (size_t)c3 * LD * ldw_b, hw);
     };
-    // epilogue operands: statistics partials of the tile's 256 token slots ([row half][part][128 x (sum, sumsq)], 3 pieces per wave),
-    // bias and column sums of the head's 192 columns (waves 0 / 1)
-    auto stage_aux = [&](int grp, int head) {
+    // epilogue operands: statistics partials of the tile's 256 token slots ([row half][part][128 x (sum, sumsq)], 3 pieces per wave:
+    // staged at the top of a tile, consumed inside its K loop), bias and column sums of the head's 192 columns (waves 0 / 1)
+    auto stage_stats = [&](int grp) {
         const int ln = qa_opaque(threadIdx.x & 63);
         const int gh = wave >> 2;
         int row = slot_row(grp, gh * 128 + 2 * ln);
@@ -154,6 +159,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
             const int part = (wave & 3) * 3 + r;
             dma(aux_lds + (unsigned)(gh * 12288 + part * 1024), sb + (size_t)part * (size_t)g.M * 8, (unsigned)(row >> 1) * 16u);
         }
+    };
+    auto stage_cols = [&](int head) {
+        const int ln = qa_opaque(threadIdx.x & 63);
         int c3 = ln >> 4;
         c3 = c3 < 3 ? c3 : 2;
         const unsigned voff = (unsigned)(c3 * LD + (ln & 15) * 4) * 4u;
@@ -199,15 +207,54 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     const unsigned char* b1 = lds + QA_BUF;
 
     int grp = L / BG_N_HEAD, head = L % BG_N_HEAD;
-    stage_aux(grp, head);
+    int tile_no = 0;
+    auto stamp = [&](int k) {
+        if (DBG == 2) {
+            if (blockIdx.x == 8 && (threadIdx.x & 255) == 0) {
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                reinterpret_cast<unsigned long long*>(g.dbg)[(tile_no * 2 + (threadIdx.x >> 8)) * 8 + k] = t;
+            }
+        }
+    };
+    // LayerNorm-fold coefficients (rstd, -mean rstd) of the lane's token of row tile i, from the staged partials -- in two light steps
+    // (sums of the twelve partials; the coefficients) that fit behind an 8-MFMA segment of the partner wave
+    float2 cf[2];
+    auto fold_sums = [&](int i) {
+        const int l31 = qa_opaque(threadIdx.x & 31);
+        const unsigned char* sg = aux + (wm >> 1) * 12288;
+        const int rg = (wm & 1) * 64 + i * 32 + l31;
+        float ps[16], pq[16];
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const float2 v = pp < FOLD_PARTS ? reinterpret_cast<const float2*>(sg + pp * 1024)[rg] : make_float2(0.f, 0.f);
+            ps[pp] = v.x; pq[pp] = v.y;
+        }
+        cf[i] = make_float2(tree16(ps), tree16(pq));
+        asm volatile("" : "+v"(cf[i].x), "+v"(cf[i].y) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fold_coeffs = [&](int i) {
+        cf[i] = ln_fold_coeffs(cf[i].x, cf[i].y, LD, g.ln_eps);
+        asm volatile("" : "+v"(cf[i].x), "+v"(cf[i].y) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue of the first tile: buffer 0 complete, A of buffer 1 in flight (as if issued in phase 6) ----
+    a_offsets(grp);
+    stage_stats(grp); stage_cols(head);
+    stage_a(0, Ab); stage_w(0, Wb + (size_t)head * 64 * ldw_b); stage_a(1, Ab + 2 * G_BK);
+    wait_vmcnt<4>();
+    bar();
     for (;;) {
-        const unsigned char* w_cur = Wb + (size_t)head * 64 * ldw_b;
-        a_offsets(grp);
-        // ---- prologue: buffer 0 complete, A of buffer 1 in flight (as if issued in phase 6) ----
-        stage_a(0, Ab); stage_w(0, w_cur); stage_a(1, Ab + 2 * G_BK);
-        wait_vmcnt<4>();
-        bar();
+        // here: buffer 0 = K-step 0 of this tile, landed and visible; A rows of K-step 1 in flight; every wave at the same barrier
+        stamp(0);
         if (late) bar();
+        stamp(1);
+        const unsigned char* w_cur = Wb + (size_t)head * 64 * ldw_b;
+        const int Ln = L + G;
+        const bool has_next = Ln < T_all;
+        const int grp_n = Ln / BG_N_HEAD, head_n = Ln % BG_N_HEAD;
+        const unsigned char* w_nxt = Wb + (size_t)head_n * 64 * ldw_b;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -215,53 +262,49 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // one iteration = K-steps t (buffer 0), t + 1 (buffer 1); kb = byte offset of K-step t inside a row
-        auto iteration = [&](unsigned kb, bool more) {
+        // one iteration = K-steps t (buffer 0), t + 1 (buffer 1).  w1: K-step t + 1 of W; more: (a2, w2) = K-step t + 2 exists
+        // (the last iteration: K-step 0 of the NEXT tile, `ha` then holds that tile's lane offsets); more3: a3 = K-step t + 3 of A
+        // (never across the tile seam: buffer 1 becomes the epilogue's); fold: this iteration computes the LayerNorm-fold
+        // coefficients of row tile `fold` in its two read-free phases (the statistics landed before the first counted wait of the tile)
+        auto iteration = [&](const unsigned char* w1, bool more, const unsigned char* a2, const unsigned char* w2, bool more3,
+                             const unsigned char* a3, int fold) {
             // phase 1
             read_b(b0, 0); __builtin_amdgcn_sched_barrier(0); read_a(b0);
-            stage_w(1, w_cur + kb + 2 * G_BK);
+            stage_w(1, w1);
             bar(); segment(0); bar();
             // phase 2
             read_b(b0, 1); read_b(b0, 2);
             bar(); segment(1); bar();
             // phase 3
-            if (more) { stage_a(0, Ab + kb + 4 * G_BK); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+            if (more) { stage_a(0, a2); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+            if (fold >= 0) fold_sums(fold);
             bar(); segment(2); bar();
             // phase 4
             read_b(b1, 0); __builtin_amdgcn_sched_barrier(0); read_a(b1);
-            if (more) stage_w(0, w_cur + kb + 4 * G_BK);
+            if (more) stage_w(0, w2);
             bar(); segment(0); bar();
             // phase 5
             read_b(b1, 1); read_b(b1, 2);
             bar(); segment(1); bar();
             // phase 6
-            if (more) { stage_a(1, Ab + kb + 6 * G_BK); wait_vmcnt<4>(); }
+            if (more3) { stage_a(1, a3); wait_vmcnt<4>(); } else if (more) { wait_vmcnt<0>(); }
+            if (fold >= 0) fold_coeffs(fold);
             bar(); segment(2); bar();
         };
-        for (int t = 0; t + 2 < KT; t += 2) iteration((unsigned)t * (2 * G_BK), true);
-        iteration((unsigned)(KT - 2) * (2 * G_BK), false);
+        for (int t = 0; t + 2 < KT; t += 2) {
+            const unsigned kb = (unsigned)t * (2 * G_BK);
+            iteration(w_cur + kb + 2 * G_BK, true, Ab + kb + 4 * G_BK, w_cur + kb + 4 * G_BK, true, Ab + kb + 6 * G_BK,
+                      t == KT - 6 ? 0 : (t == KT - 4 ? 1 : -1));
+        }
+        if (has_next) a_offsets(grp_n);                           // the last iteration stages A rows of the next tile only
+        iteration(w_cur + (unsigned)(KT - 1) * (2 * G_BK), has_next, Ab, w_nxt, false, Ab, -1);
         if (!late) bar();                                         // both wave groups enter the epilogue together
+        stamp(2);
 
         // ---------------- epilogue ----------------
         const int ln = qa_opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
-        float2 cf[2];
-        {
-            const unsigned char* sg = aux + (wm >> 1) * 12288;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rg = (wm & 1) * 64 + i * 32 + l31;
-                float ps[16], pq[16];
-#pragma unroll
-                for (int pp = 0; pp < 16; ++pp) {
-                    const float2 v = pp < FOLD_PARTS ? reinterpret_cast<const float2*>(sg + pp * 1024)[rg] : make_float2(0.f, 0.f);
-                    ps[pp] = v.x; pq[pp] = v.y;
-                }
-                cf[i] = ln_fold_coeffs(tree16(ps), tree16(pq), LD, g.ln_eps);
-                asm volatile("" : "+v"(cf[i].x), "+v"(cf[i].y) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
         T* dbg = reinterpret_cast<T*>(g.dbg);
+        stamp(3);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int tc0 = wn * 96 + j * 32;                     // wave-uniform: first tile column of this column tile
@@ -284,13 +327,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                     pk.v = E::pack4(v[0], v[1], v[2], v[3]);
                     const int R = wm * 64 + i * 32 + l31;         // token slot of the tile
                     if (c3 < 2) {
-                        *reinterpret_cast<uint2*>(lds + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
+                        *reinterpret_cast<uint2*>(lds + QA_QIMG + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
                     } else {
                         T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + (R / S) * (64 * VS) + (R % S);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) vt[(d + e) * VS] = pk.t[e];
                     }
-                    if (DBG) {
+                    if (DBG == 1) {
                         const int smp = grp * SPT + R / S, tok = R % S;
                         if (smp < g.B && tok < g.N)
                             *reinterpret_cast<uint2*>(dbg + (size_t)(smp * g.N + tok) * (3 * LD) + c3 * LD + head * 64 + d) = pk.u;
@@ -298,17 +341,16 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 }
             }
         }
+        stamp(4);
         lds_done_bar();                                           // images complete; nobody reads the aux region any more
+        stamp(5);
 
-        // the next tile of this workgroup: its epilogue operands travel while this tile's attention runs
-        const int Ln = L + G;
-        const bool has_next = Ln < T_all;
-        const int grp_n = Ln / BG_N_HEAD, head_n = Ln % BG_N_HEAD;
-        if (has_next) stage_aux(grp_n, head_n);
+        if (has_next) stage_cols(head_n);                        // bias / column sums of the next tile travel while the attention runs
 
         // ---- attention: 32 queries of one sample per wave (attn16_kernel, attn.hip) ----
         {
-            const int slot = wave / WPS, qb = wave % WPS;
+            const int wq = wm * 2 + wn;                            // (a bijection of the waves; wm = the sample's row block)
+            const int slot = wq / WPS, qb = wq % WPS;
             const int smp = grp * SPT + slot;
             if (smp < g.B) {
                 const int h = hq;
@@ -337,32 +379,37 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                         s = E::mfma(kf, qf[ks], s);
                     }
                     // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query l31
+                    // (attn16_kernel adds a 0 / -inf bias to every score; adding 0 changes nothing the softmax can see, so only a
+                    //  sub-tile that holds keys past the sample's end pays for it)
+                    if (sub * 32 + 32 > g.N) {
+                        const int thr = g.N - sub * 32 - 4 * h;       // register r is dead iff (r&3) + 8 (r>>2) >= thr
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[r] += ((r & 3) + 8 * (r >> 2)) >= thr ? -INFINITY : 0.f;
+                    }
                     float mloc = -INFINITY;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int key = sub * 32 + 8 * g4 + 4 * h + e;
-                            s[4 * g4 + e] += key >= g.N ? -INFINITY : 0.f;
-                        }
+                    for (int g4 = 0; g4 < 4; ++g4)
                         mloc = fmaxf(mloc, fmaxf(fmaxf(s[4 * g4 + 0], s[4 * g4 + 1]), fmaxf(s[4 * g4 + 2], s[4 * g4 + 3])));
-                    }
                     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
                     const float m_new = fmaxf(m_run, mloc);
                     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                    const float alpha = __expf(m_run - m_use);
                     float psum = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         s[r] = __expf(s[r] - m_use);
                         psum += s[r];
                     }
-                    l_run = l_run * alpha + psum;
+                    if (sub == 0) {                               // (running sum and O are 0: their rescaling by alpha = 0 leaves 0)
+                        l_run = psum;
+                    } else {
+                        const float alpha = __expf(m_run - m_use);
+                        l_run = l_run * alpha + psum;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    }
                     m_run = m_new;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
                         V8 pb;
@@ -398,9 +445,14 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 }
             }
         }
+        stamp(6);
         if (!has_next) break;
-        lds_done_bar();                                           // the images are consumed: the ring may be re-staged
+        lds_done_bar();                                           // the images are consumed: buffer 1 and the statistics' place are free
+        stamp(7);
+        ++tile_no;
         L = Ln; grp = grp_n; head = head_n;
+        stage_a(1, Ab + 2 * G_BK);                                // K-step 1 of the new tile (`ha` is already this tile's)
+        stage_stats(grp);
     }
 }
 
@@ -426,12 +478,15 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
     const int grid = tiles < 256 ? tiles : 256;
     const bool f16 = dtype == BG_F16;
 #define QA_LAUNCH(F, SS, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, D>), dim3(grid), dim3(512), 0, s, g)
-    if (g.dbg) {                                                   // (tests: the q|k|v image is written out as well)
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, true); else QA_LAUNCH(false, 64, true); }
-        else { if (f16) QA_LAUNCH(true, 32, true); else QA_LAUNCH(false, 32, true); }
+    if (g.dbg && g.ln_eps < 0.f) {                                 // (timing stamps: experiments only)
+        QkvAttnArgs h = g; h.ln_eps = -g.ln_eps;
+        hipLaunchKernelGGL((qkv_attn_kernel<false, 64, 2>), dim3(grid), dim3(512), 0, s, h);
+    } else if (g.dbg) {                                            // (tests: the q|k|v image is written out as well)
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, 1); else QA_LAUNCH(false, 64, 1); }
+        else { if (f16) QA_LAUNCH(true, 32, 1); else QA_LAUNCH(false, 32, 1); }
     } else {
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, false); else QA_LAUNCH(false, 64, false); }
-        else { if (f16) QA_LAUNCH(true, 32, false); else QA_LAUNCH(false, 32, false); }
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, 0); else QA_LAUNCH(false, 64, 0); }
+        else { if (f16) QA_LAUNCH(true, 32, 0); else QA_LAUNCH(false, 32, 0); }
     }
 #undef QA_LAUNCH
     return launch_status("qkv_attn");
