@@ -87,3 +87,15 @@ for B, N in ((512, 60), (256, 60), (512, 30), (256, 30), (1024, 60)):
     fl = 2.0 * M * 768 * 2304
     print(f"B={B:5d} N={N:3d} (M={M:6d}): GEMM {t_g:7.1f} us ({fl / t_g / 1e6:5.0f} TF) + attention {t_a:6.1f} us = {t_g + t_a:7.1f} us;  "
           f"fused {t_f:7.1f} us ({fl / t_f / 1e6:5.0f} TF on the GEMM FLOPs)  ratio {t_f / (t_g + t_a):.3f}", flush=True)
+
+
+# ---- operand data and the clock: the same launches on random, constant and zero operands (a kernel that is bound by what the part
+# may draw, not by its schedule, runs faster the fewer bits toggle) ----
+B, N = 512, 60
+a, w, b, cs, stats = build(B, N, dt)
+M = B * N
+for name, aa, ww in (("random operands", a, w), ("A = 1.0, W random", torch.ones_like(a), w), ("A = 0, W = 0", torch.zeros_like(a), torch.zeros_like(w))):
+    t_f = statistics.median(timed(lambda: ops.qkv_attention(aa, ww, b, cs, stats, B, N), n=40) for _ in range(R))
+    t_g = statistics.median(timed(lambda: ops.linear_ex(aa, ww, b, stats_in=stats, colsum=cs), n=40) for _ in range(R))
+    t_p = statistics.median(timed(lambda: ops.linear(aa, ww, b, out_dtype=dt), n=40) for _ in range(R))
+    print(f"{name:20s}: fused {t_f:7.1f} us   256 x 256 GEMM, LayerNorm fold {t_g:7.1f} us, plain {t_p:7.1f} us", flush=True)
