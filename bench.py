@@ -173,6 +173,81 @@ def cpu_baseline(steps=2, warmup=1):
             "calibration_s_per_sample_step": {str(k): round(v, 3) for k, v in calib.items()}}
 
 
+def sustained_clock_extra(dev, secs=0.6):
+    """Reported BESIDE the headline: what the part sustains under the MFMA-bound launch of the step (the fused QKV + attention
+    launch of SurfPosNet at 512 x 60) -- microseconds per launch, package power and shader clock (hwmon of THIS device), with the
+    bench's random operands and with all-zero operands (the same instruction stream, no bits toggling).  The roofline's MFMA peak
+    assumes 2.4 GHz; with random 16-bit operands the 1400 W cap leaves less."""
+    import glob
+    import threading
+    from brepgen_amd import _lib
+    lib = _lib.load()
+    pr = torch.cuda.get_device_properties(dev)
+    want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") else None
+    sens = {}
+    for card in sorted(glob.glob("/sys/class/drm/card*")):
+        if "-" in os.path.basename(card) or (want and want not in os.path.realpath(os.path.join(card, "device"))):
+            continue
+        for hw in glob.glob(os.path.join(card, "device", "hwmon", "hwmon*")):
+            for key, names in (("W", ("power1_average", "power1_input")), ("MHz", ("freq1_input",)), ("cap_W", ("power1_cap",))):
+                for n in names:
+                    if key not in sens and os.path.exists(os.path.join(hw, n)):
+                        sens[key] = os.path.join(hw, n)
+
+    def read(key):
+        try:
+            return int(open(sens[key]).read()) / 1e6
+        except (KeyError, OSError, ValueError):
+            return None
+
+    B, N = B_PER_GPU, N_FACE
+    M = B * N
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, 768, generator=g) * 2
+    grp = x.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().to(dev)
+    a = x.to(torch.bfloat16).to(dev)
+    w = (torch.randn(2304, 768, generator=g) * 0.04).to(torch.bfloat16).to(dev)
+    b = torch.randn(2304, generator=g).to(dev)
+    cs = w.float().sum(1).contiguous()
+    out = torch.empty(M, 768, device=dev, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {"launch": "bg_qkv_attn_fwd, 512 x 60 tokens, bf16 (110.1 GFLOP)", "power_cap_W": read("cap_W")}
+    for name, aa, ww in (("random_operands", a, w), ("zero_operands", torch.zeros_like(a), torch.zeros_like(w))):
+        def fn():
+            _lib.check(lib.bg_qkv_attn_fwd(aa.data_ptr(), ww.data_ptr(), b.data_ptr(), cs.data_ptr(), stats.data_ptr(), out.data_ptr(),
+                                           None, B, N, _lib.BG_BF16, 1e-5, st), "bg_qkv_attn_fwd")
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                samples.append((read("W"), read("MHz")))
+                time.sleep(0.03)
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        th = threading.Thread(target=poll)
+        th.start()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, n = time.perf_counter(), 0
+        e0.record()
+        while time.perf_counter() - t0 < secs:
+            for _ in range(50):
+                fn()
+            n += 50
+            torch.cuda.synchronize()
+        e1.record()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join()
+        tail = samples[len(samples) // 2:]
+        med = lambda v: (sorted(v)[len(v) // 2] if v else None)
+        us = e0.elapsed_time(e1) / n * 1e3
+        res[name] = {"us_per_launch": round(us, 1), "tflops": round(110.1e9 / us / 1e6, 1),
+                     "power_W": med([p for p, _ in tail if p is not None]), "shader_clock_MHz": med([f for _, f in tail if f is not None])}
+    return res
+
+
 def edge_net_extra(dev, evals=2):
     """Reported BESIDE the headline (never part of `value`): one eps-evaluation of the edge nets at the shapes of
     BASELINE configs[2] / configs[3] / configs[4] (the last one guided: conditional + unconditional rows, fp16) -- where
@@ -567,7 +642,7 @@ def main():
             for k, r in sorted(rows.items(), key=lambda kv: -kv[1]["total_ms"])[:4] if r["flops"]}
         # every GEMM kernel of the step together (the 256 x 256 kernel takes the row panels that fill whole rounds, the
         # 128 x 128 kernel the rest and the residual-stream GEMMs): executed FLOPs / their summed durations
-        gem = [r for k, r in rows.items() if k.startswith("gemm16")]
+        gem = [r for k, r in rows.items() if k.startswith("gemm16") or k.startswith("qkv_attn")]   # (the fused launch: QKV GEMM + 5 % attention FLOPs)
         if gem:
             fl, ms = sum(r["flops"] for r in gem), sum(r["total_ms"] for r in gem)
             roofline["all_16bit_gemm_kernels"] = {"tflops": round(fl / ms / 1e9, 1), "frac": round(fl / ms / 1e9 / MFMA_PEAK_TFLOPS, 4),
@@ -577,6 +652,10 @@ def main():
         ldm = None
         torch.cuda.empty_cache()
         extra["edge_nets"] = edge_net_extra(dev)
+        try:
+            extra["sustained_clock"] = sustained_clock_extra(dev)
+        except Exception as e:
+            extra["sustained_clock"] = {"error": repr(e)}
         try:
             extra["cascade_cfg3"] = cascade_extra()
         except Exception as e:                                       # reported, never fatal for the headline

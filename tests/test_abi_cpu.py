@@ -188,13 +188,15 @@ def test_p256_kernels_do_not_spill():
         assert sc <= (8 if split else 0), (n, sc)
 
 
-def test_split_pipe_kernel_does_not_spill():
-    """csrc/gemm_split.hip runs at the 256-VGPR limit of two waves per SIMD (two accumulator sets + the slab in flight); a spill
-    would put scratch traffic into K-steps whose waits are placed by hand."""
+@pytest.mark.parametrize("src", ["gemm_split.hip", "qkv_attn.hip"])
+def test_hand_scheduled_kernels_do_not_spill(src):
+    """csrc/gemm_split.hip runs at the 256-VGPR limit of two waves per SIMD (two accumulator sets + the slab in flight),
+    csrc/qkv_attn.hip keeps 96 accumulators + 80 fragment registers + the fold temporaries live in its K loop; a spill would put
+    scratch traffic (and hipcc's vmcnt(0) after every reload) into K-steps whose waits are placed by hand."""
     import re
     import subprocess
     from brepgen_amd import build as b
-    r = subprocess.run([b._hipcc(), *b.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(b.CSRC, "gemm_split.hip"),
+    r = subprocess.run([b._hipcc(), *b.FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(b.CSRC, src),
                         "-o", os.devnull], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]

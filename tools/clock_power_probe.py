@@ -114,9 +114,18 @@ w = (torch.randn(2304, 768, generator=g) * 0.04).to(dt).cuda()
 b = torch.randn(2304, generator=g).cuda()
 cs = w.float().sum(1).contiguous()
 print("idle:", read_sensors(), flush=True)
-for name, aa, ww in (("random operands", a, w), ("zero operands", torch.zeros_like(a), torch.zeros_like(w)), ("random operands", a, w)):
-    for kname, fn in (("fused QKV + attention", lambda: ops.qkv_attention(aa, ww, b, cs, stats, B, N)),
-                      ("256 x 256 GEMM, LayerNorm fold", lambda: ops.linear_ex(aa, ww, b, stats_in=stats, colsum=cs))):
+K2 = 1024
+hi, lo = a.clone(), (x - a.float().cpu()).to(dt).cuda()
+a2 = (torch.randn(M, K2, generator=g) * 0.5).to(dt).cuda()
+w2 = (torch.randn(768, K2, generator=g) * 0.04).to(dt).cuda()
+b2 = torch.randn(768, generator=g).cuda()
+for name, zero in (("random operands", False), ("zero operands", True), ("random operands", False)):
+    aa, ww = (torch.zeros_like(a), torch.zeros_like(w)) if zero else (a, w)
+    a2z, w2z = (torch.zeros_like(a2), torch.zeros_like(w2)) if zero else (a2, w2)
+    h, l = (torch.zeros_like(hi), torch.zeros_like(lo)) if zero else (hi.clone(), lo.clone())
+    for kname, fl, fn in (("fused QKV + attention", 2.0 * M * 768 * 2304, lambda: ops.qkv_attention(aa, ww, b, cs, stats, B, N)),
+                          ("256 x 256 GEMM, LayerNorm fold (QKV)", 2.0 * M * 768 * 2304, lambda: ops.linear_ex(aa, ww, b, stats_in=stats, colsum=cs)),
+                          ("FFN2, split residual in place", 2.0 * M * 768 * K2,
+                           lambda: ops.linear_ex(a2z, w2z, b2, split_out=True, res=(h, l), want_stats=True, inplace=True))):
         us, watts, mhz, raw = sampled(fn, SECS)
-        fl = 2.0 * M * 768 * 2304
-        print(f"{kname:32s} {name:16s}: {us:7.1f} us per launch ({fl / us / 1e6:5.0f} TF)  power {watts} W  shader clock {mhz} MHz  {raw or ''}", flush=True)
+        print(f"{kname:38s} {name:16s}: {us:7.1f} us per launch ({fl / us / 1e6:5.0f} TF)  power {watts} W  shader clock {mhz} MHz  {raw or ''}", flush=True)
