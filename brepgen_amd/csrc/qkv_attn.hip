@@ -7,13 +7,15 @@
 //
 // As two launches the 256 x 256 GEMM writes q|k|v (4.6 KB per token) and the attention kernel reads it back: 283 MB per layer at
 // the face LDM's 30 720 tokens, all of it inside the GEMM's store burst (every CU reaches its epilogue at the same time) and the
-// attention kernel's read -- neither overlaps MFMA work.  Here q|k|v of one (sample group, head) never leave the CU.
+// attention kernel's read -- neither overlaps MFMA work.  Here q|k|v of one (sample group, head) never leave the CU: the launch
+// takes what the GEMM alone took (profiles/r04/qkv_attn_check_*.log: 131 vs 127 + 37 us at 512 x 60 tokens).
 //
 // Tile = 256 token slots x 192 columns (q, k, v of ONE head, 64 each) x K-steps of 64; the 256 slots are 256 / S samples of S = 64
 // (or 32) slots each, a sample's N <= S tokens followed by copies of its last token (never stored, masked as keys) -- so the rows
 // of a tile are whole samples and a wave's 32 queries belong to one of them.  8 waves as 4 (rows) x 2 (columns), 64 x 96 per wave
-// = 2 x 3 MFMA tiles, transposed product (weights as the A operand: a lane owns one token).  LDS: two K-step buffers of 56 KiB
-// (A rows 0-127 | A rows 128-255 | W rows q, k, v) + 48 KiB for the epilogue operands; one workgroup per CU.
+// = 2 x 3 MFMA tiles, transposed product (weights as the A operand: a lane owns one token); one persistent workgroup per CU walks
+// an XCD-aware list of (sample group, head) tiles.  LDS (160 KiB): buffer 0 | buffer 1 (one K-step each: A rows 0-127 | A rows
+// 128-255 | W rows q, k, v = 56 KiB) | 24 KiB statistics partials | ... | bias + column sums (2 KiB at the end).
 //
 // K loop: the phase discipline of gemm_p256.hip on this geometry -- waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one
 // wave is in an 8-MFMA segment while the other reads fragments and issues LDS-DMA.  Six phases per iteration (two K-steps), phase =
@@ -27,12 +29,18 @@
 //   6   --                        buffer 1, A (t+3): 4 pieces          vmcnt(4)     column tile 2     -> buffer 0 (t+2) landed
 // Write-after-read: a region last read in phase R (by any wave, the late group included) is re-staged from phase R + 2 on -- A is
 // last read in phases 1 / 4, W in 2 / 5.  Read-after-write: the counted wait sits before the first barrier of phases 3 / 6, the
-// first read of that buffer one phase later (gemm_p256.hip: the same argument).
+// first read of that buffer one phase later (gemm_p256.hip: the same argument).  The read-free phases 3 / 6 of two late iterations
+// also carry the LayerNorm-fold coefficients of the lane's two tokens (sums of the twelve staged partials, then rstd and
+// -mean rstd: two light steps each, behind the partner wave's MFMA segment).  In the last iteration of a tile (t+2) is K-step 0 of
+// the NEXT tile and nothing is staged into buffer 1: the seam costs no prologue (measured: 2.5-3.4 k of 36 k cycles before).
 //
-// Epilogue (all eight waves together): LayerNorm-fold coefficients of the lane's two tokens from the staged statistics partials,
-// fold + bias + 16-bit rounding exactly as P_FOLD16, then q, k (row-major, the attention kernel's swizzled K-tile layout) and v
-// (transposed per sample, that kernel's V^T layout) go to the LDS the ring occupied; one barrier; every wave runs the attention
-// of 32 queries of one sample -- attn16_kernel's arithmetic, instruction for instruction -- and stores 32 x 64 outputs.
+// Epilogue (all eight waves together): fold + bias + 16-bit rounding exactly as P_FOLD16, then q, k (row-major, the attention
+// kernel's swizzled K-tile layout) and v (transposed per sample, that kernel's V^T layout) go to LDS -- buffer 1 and the place of
+// the statistics, consumed by then; buffer 0 already holds the next tile's first K-step -- one barrier; every wave runs the
+// attention of 32 queries of one sample -- attn16_kernel's arithmetic (the 0 / -inf key bias only where a sub-tile holds dead
+// keys, no rescaling of the empty accumulator: neither changes a bit) -- and stores 32 x 64 outputs; one barrier.
+// Per tile (s_memtime, profiles/r04/qkv_attn_stamps_*.log): K loop 21 k cycles for 18.4 k cycles of MFMA issue per SIMD, fold +
+// images 3.5-4.8 k, attention 4.4-7 k (VALU-issue-bound: two waves per SIMD), barriers 1.5 + 2.6 k.
 // Results are bit-identical to gemm (P_FOLD16) + attention (tests/test_gpu_round4.py).
 #include "gemm16.h"
 #include <math.h>
@@ -64,7 +72,7 @@ __device__ __forceinline__ int qa_opaque(int x) {
     return x;
 }
 
-template <bool F16, int S, int DBG = 0>
+template <bool F16, int S, bool DBG = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     using E = Elem<F16>;
     using T = typename E::T;
@@ -207,15 +215,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     const unsigned char* b1 = lds + QA_BUF;
 
     int grp = L / BG_N_HEAD, head = L % BG_N_HEAD;
-    int tile_no = 0;
-    auto stamp = [&](int k) {
-        if (DBG == 2) {
-            if (blockIdx.x == 8 && (threadIdx.x & 255) == 0) {
-                const unsigned long long t = __builtin_amdgcn_s_memtime();
-                reinterpret_cast<unsigned long long*>(g.dbg)[(tile_no * 2 + (threadIdx.x >> 8)) * 8 + k] = t;
-            }
-        }
-    };
     // LayerNorm-fold coefficients (rstd, -mean rstd) of the lane's token of row tile i, from the staged partials -- in two light steps
     // (sums of the twelve partials; the coefficients) that fit behind an 8-MFMA segment of the partner wave
     float2 cf[2];
@@ -247,9 +246,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     bar();
     for (;;) {
         // here: buffer 0 = K-step 0 of this tile, landed and visible; A rows of K-step 1 in flight; every wave at the same barrier
-        stamp(0);
         if (late) bar();
-        stamp(1);
         const unsigned char* w_cur = Wb + (size_t)head * 64 * ldw_b;
         const int Ln = L + G;
         const bool has_next = Ln < T_all;
@@ -299,12 +296,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         if (has_next) a_offsets(grp_n);                           // the last iteration stages A rows of the next tile only
         iteration(w_cur + (unsigned)(KT - 1) * (2 * G_BK), has_next, Ab, w_nxt, false, Ab, -1);
         if (!late) bar();                                         // both wave groups enter the epilogue together
-        stamp(2);
 
         // ---------------- epilogue ----------------
         const int ln = qa_opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
         T* dbg = reinterpret_cast<T*>(g.dbg);
-        stamp(3);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int tc0 = wn * 96 + j * 32;                     // wave-uniform: first tile column of this column tile
@@ -333,7 +328,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) vt[(d + e) * VS] = pk.t[e];
                     }
-                    if (DBG == 1) {
+                    if (DBG) {
                         const int smp = grp * SPT + R / S, tok = R % S;
                         if (smp < g.B && tok < g.N)
                             *reinterpret_cast<uint2*>(dbg + (size_t)(smp * g.N + tok) * (3 * LD) + c3 * LD + head * 64 + d) = pk.u;
@@ -341,9 +336,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 }
             }
         }
-        stamp(4);
         lds_done_bar();                                           // images complete; nobody reads the aux region any more
-        stamp(5);
 
         if (has_next) stage_cols(head_n);                        // bias / column sums of the next tile travel while the attention runs
 
@@ -445,11 +438,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 }
             }
         }
-        stamp(6);
         if (!has_next) break;
         lds_done_bar();                                           // the images are consumed: buffer 1 and the statistics' place are free
-        stamp(7);
-        ++tile_no;
         L = Ln; grp = grp_n; head = head_n;
         stage_a(1, Ab + 2 * G_BK);                                // K-step 1 of the new tile (`ha` is already this tile's)
         stage_stats(grp);
@@ -478,15 +468,12 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
     const int grid = tiles < 256 ? tiles : 256;
     const bool f16 = dtype == BG_F16;
 #define QA_LAUNCH(F, SS, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, D>), dim3(grid), dim3(512), 0, s, g)
-    if (g.dbg && g.ln_eps < 0.f) {                                 // (timing stamps: experiments only)
-        QkvAttnArgs h = g; h.ln_eps = -g.ln_eps;
-        hipLaunchKernelGGL((qkv_attn_kernel<false, 64, 2>), dim3(grid), dim3(512), 0, s, h);
-    } else if (g.dbg) {                                            // (tests: the q|k|v image is written out as well)
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, 1); else QA_LAUNCH(false, 64, 1); }
-        else { if (f16) QA_LAUNCH(true, 32, 1); else QA_LAUNCH(false, 32, 1); }
+    if (g.dbg) {                                            // (tests: the q|k|v image is written out as well)
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, true); else QA_LAUNCH(false, 64, true); }
+        else { if (f16) QA_LAUNCH(true, 32, true); else QA_LAUNCH(false, 32, true); }
     } else {
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, 0); else QA_LAUNCH(false, 64, 0); }
-        else { if (f16) QA_LAUNCH(true, 32, 0); else QA_LAUNCH(false, 32, 0); }
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, false); else QA_LAUNCH(false, 64, false); }
+        else { if (f16) QA_LAUNCH(true, 32, false); else QA_LAUNCH(false, 32, false); }
     }
 #undef QA_LAUNCH
     return launch_status("qkv_attn");
