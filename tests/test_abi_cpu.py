@@ -75,6 +75,20 @@ def test_gemm_ex_rejects_inconsistent_epilogue_options():
     assert lib.bg_embed_ln_silu_fwd(fake, 5, 4, 5, fake, fake, fake, fake, fake, _lib.BG_BF16, 1e-5, None) == -2   # k = 5
 
 
+def test_fused_qkv_attention_validates_before_launching():
+    """bg_qkv_attn_fwd covers unmasked batches of equally long sequences of an EVEN length <= 64 with 16-bit operands and the
+    LayerNorm-fold operands present; everything else is an argument error (the two-launch path serves it), never a launch."""
+    lib = _lib.load()
+    fake = 0x10000
+    f = lambda **kw: lib.bg_qkv_attn_fwd(kw.get("x", fake), fake, kw.get("bias", fake), kw.get("colsum", fake), kw.get("stats", fake),
+                                         fake, None, kw.get("B", 4), kw.get("N", 60), kw.get("dtype", _lib.BG_BF16), 1e-5, None)
+    for kw in (dict(N=33), dict(N=66), dict(N=0), dict(dtype=_lib.BG_F32), dict(stats=None), dict(colsum=None), dict(bias=None),
+               dict(stats=fake + 8)):
+        assert f(**kw) == -2 and lib.bg_last_error(), kw                 # BG_E_SHAPE
+    assert f(x=None) == -1                                                # BG_E_ARG
+    assert f(x=fake + 2) == -5                                            # BG_E_ALIGN
+
+
 def test_workspace_bytes_scales_with_tokens():
     lib = _lib.load()
     a = lib.bg_workspace_bytes(_lib.BG_SURFZ, 512, 60, 1, _lib.BG_BF16)
