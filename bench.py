@@ -215,8 +215,8 @@ def sustained_clock_extra(dev, secs=0.6):
     res = {"launch": "bg_qkv_attn_fwd, 512 x 60 tokens, bf16 (110.1 GFLOP)", "power_cap_W": read("cap_W")}
     for name, aa, ww in (("random_operands", a, w), ("zero_operands", torch.zeros_like(a), torch.zeros_like(w))):
         def fn():
-            _lib.check(lib.bg_qkv_attn_fwd(aa.data_ptr(), ww.data_ptr(), b.data_ptr(), cs.data_ptr(), stats.data_ptr(), out.data_ptr(),
-                                           None, B, N, _lib.BG_BF16, 1e-5, st), "bg_qkv_attn_fwd")
+            _lib.check(lib.bg_qkv_attn_fwd(aa.data_ptr(), ww.data_ptr(), b.data_ptr(), cs.data_ptr(), stats.data_ptr(), None,
+                                           out.data_ptr(), None, B, N, _lib.BG_BF16, 1e-5, st), "bg_qkv_attn_fwd")
         samples, stop = [], threading.Event()
 
         def poll():

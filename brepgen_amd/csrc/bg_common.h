@@ -267,11 +267,11 @@ int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, co
 // keys; key_pad is ignored); otherwise sample b owns rows b*N .. b*N+N-1 and key_pad marks the padded keys.
 int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype, hipStream_t s,
               const int* offsets = nullptr, double pairs_hint = 0.0, double rows_hint = 0.0);
-// QKV (LayerNorm fold) + attention of short, equally long, unmasked sequences in one launch (qkv_attn.hip)
+// QKV (LayerNorm fold) + attention of short, equally long sequences (key_pad: optional [B, N] mask) in one launch (qkv_attn.hip)
 bool qkv_attn_eligible(int B, int N, int dtype, const void* stats_in, const void* colsum, const void* bias);
 bool qkv_attn_worthwhile(int B, int N);      // enough (sample group, head) tiles to fill the chip
 int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
-                  int B, int N, int dtype, float ln_eps, hipStream_t s);
+                  const uint8_t* key_pad, int B, int N, int dtype, float ln_eps, hipStream_t s);
 
 // valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
 // covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),

@@ -275,7 +275,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
 
     // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
-    const bool fused_qkv = c.fold && !varlen && key_pad == nullptr && g_tune[TUNE_QKV_ATTN] != 1 &&
+    const bool fused_qkv = c.fold && !varlen && g_tune[TUNE_QKV_ATTN] != 1 &&
                            qkv_attn_eligible(B, N, c.dtype, c.stats, w->layers[0].qkv_colsum, w->layers[0].b_qkv) &&
                            (g_tune[TUNE_QKV_ATTN] == 2 || qkv_attn_worthwhile(B, N));
     for (int li = 0; c.fold && li < w->n_layer; ++li) {
@@ -285,8 +285,8 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
         qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
         if (fused_qkv) {
-            // short, equally long, unmasked sequences (SurfPosNet): q|k|v never leave the CU (qkv_attn.hip; bit-identical)
-            if ((rc = qkv_attention(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, B, N, c.dtype, 1e-5f, s))) return rc;
+            // short, equally long sequences (SurfPosNet; SurfZNet executed densely): q|k|v never leave the CU (qkv_attn.hip; bit-identical)
+            if ((rc = qkv_attention(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, key_pad, B, N, c.dtype, 1e-5f, s))) return rc;
         } else {
             if ((rc = gemm(qkv, c.dtype, s))) return rc;
             if ((rc = attention(c.R, key_pad, c.H, B, N, c.dtype, s, c.offsets, c.pairs_hint, c.rows_hint))) return rc;

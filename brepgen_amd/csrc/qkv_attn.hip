@@ -1,5 +1,6 @@
 // QKV projection (LayerNorm folded) + multi-head self-attention of one encoder layer in ONE launch, for batches of short,
-// equally long sequences without a key-padding mask (the face LDM's SurfPosNet: 30 / 60 tokens per sample, network.py:1076-1078 ->
+// equally long sequences, with or without a key-padding mask (the face LDM's SurfPosNet: 30 / 60 tokens per sample; the dense
+// execution of SurfZNet; network.py:1076-1078 ->
 // torch/nn/modules/transformer.py + MultiheadAttention):
 //
 //   q|k|v[m, :] = T(rstd_m * (x_m . W'^T) - mean_m rstd_m colsum + b')        (the P_FOLD16 epilogue of gemm_p256.hip)
@@ -53,6 +54,8 @@ constexpr int QA_AUX = QA_RING, QA_BIAS = QA_LDS - QA_AUX - 2048, QA_CSUM = QA_B
 // epilogue images: buffer 1 and the statistics' place (consumed inside the K loop) -- buffer 0 already holds K-step 0 of the next tile
 constexpr int QA_QIMG = QA_BUF, QA_KIMG = QA_QIMG + 32768, QA_VIMG = QA_KIMG + 32768;
 
+constexpr int QA_MB = QA_AUX + QA_BIAS - 1024;             // 256 floats: additive key bias (0 / -inf) of the tile's slots (key-padding mask given)
+static_assert(QA_VIMG + 8 * 64 * 36 * 2 <= QA_MB && QA_VIMG + 4 * 64 * 68 * 2 <= QA_MB, "the V^T image ends below the key bias");
 static_assert(QA_VIMG + 8 * 64 * 36 * 2 <= QA_AUX + QA_BIAS && QA_VIMG + 4 * 64 * 68 * 2 <= QA_AUX + QA_BIAS, "the V^T image ends below the bias / column sums");
 
 struct QkvAttnArgs {
@@ -63,6 +66,7 @@ struct QkvAttnArgs {
     const float* stats_in;    // [12][M][2] (sum, sum of squares) per 64-column part
     void* out;                // [M, 768] attention output (16-bit)
     void* dbg;                // optional [M, 2304]: the q|k|v a two-launch run would have written (tests)
+    const uint8_t* key_pad;   // optional [B, N]: 1 = padded key (dense execution of a masked net); queries are computed at every position
     int B, N, M;
     float ln_eps;
 };
@@ -72,7 +76,7 @@ __device__ __forceinline__ int qa_opaque(int x) {
     return x;
 }
 
-template <bool F16, int S, bool DBG = false>
+template <bool F16, int S, bool MASK, bool DBG = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     using E = Elem<F16>;
     using T = typename E::T;
@@ -300,6 +304,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         // ---------------- epilogue ----------------
         const int ln = qa_opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
         T* dbg = reinterpret_cast<T*>(g.dbg);
+        float key_bias = 0.f;                                    // (MASK) slot threadIdx.x of the tile: requested now, written to LDS after the images
+        if (MASK && threadIdx.x < 256) {
+            const int smp = grp * SPT + (int)threadIdx.x / S, key = (int)threadIdx.x % S;
+            const bool inside = smp < g.B && key < g.N;
+            const uint8_t pad = inside ? g.key_pad[(size_t)smp * g.N + key] : (uint8_t)1;
+            key_bias = pad ? -INFINITY : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int tc0 = wn * 96 + j * 32;                     // wave-uniform: first tile column of this column tile
@@ -336,6 +347,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 }
             }
         }
+        if (MASK && threadIdx.x < 256) reinterpret_cast<float*>(lds + QA_MB)[threadIdx.x] = key_bias;
         lds_done_bar();                                           // images complete; nobody reads the aux region any more
 
         if (has_next) stage_cols(head_n);                        // bias / column sums of the next tile travel while the attention runs
@@ -374,7 +386,14 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                     // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query l31
                     // (attn16_kernel adds a 0 / -inf bias to every score; adding 0 changes nothing the softmax can see, so only a
                     //  sub-tile that holds keys past the sample's end pays for it)
-                    if (sub * 32 + 32 > g.N) {
+                    if (MASK) {                                   // the sample's padded keys (and the slots past its end): attn16_kernel's mb
+                        const float* mb = reinterpret_cast<const float*>(lds + QA_MB) + slot * S + sub * 32 + 4 * h;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const float4 mbv = *reinterpret_cast<const float4*>(mb + 8 * g4);
+                            s[4 * g4 + 0] += mbv.x; s[4 * g4 + 1] += mbv.y; s[4 * g4 + 2] += mbv.z; s[4 * g4 + 3] += mbv.w;
+                        }
+                    } else if (sub * 32 + 32 > g.N) {
                         const int thr = g.N - sub * 32 - 4 * h;       // register r is dead iff (r&3) + 8 (r>>2) >= thr
 #pragma unroll
                         for (int r = 0; r < 16; ++r) s[r] += ((r & 3) + 8 * (r >> 2)) >= thr ? -INFINITY : 0.f;
@@ -446,7 +465,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     }
 }
 
-// uniform short sequences, no key mask, LayerNorm fold operands present
+// uniform short sequences (a key-padding mask over them is fine), LayerNorm fold operands present
 bool qkv_attn_eligible(int B, int N, int dtype, const void* stats_in, const void* colsum, const void* bias) {
     return (dtype == BG_BF16 || dtype == BG_F16) && B > 0 && N >= 2 && N <= 64 && (N & 1) == 0 && stats_in && colsum && bias &&
            (((size_t)stats_in) & 15) == 0 && (size_t)B * N * BG_D_MODEL * 2 < 0xffffffffull;
@@ -467,33 +486,38 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
                    rows * (2.0 * BG_D_MODEL * 2 + FOLD_PARTS * 8.0) + 2.0 * 3 * BG_D_MODEL * BG_D_MODEL + 2 * 4.0 * 3 * BG_D_MODEL, s);
     const int grid = tiles < 256 ? tiles : 256;
     const bool f16 = dtype == BG_F16;
-#define QA_LAUNCH(F, SS, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, D>), dim3(grid), dim3(512), 0, s, g)
-    if (g.dbg) {                                            // (tests: the q|k|v image is written out as well)
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, true); else QA_LAUNCH(false, 64, true); }
-        else { if (f16) QA_LAUNCH(true, 32, true); else QA_LAUNCH(false, 32, true); }
+#define QA_LAUNCH(F, SS, MK, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, MK, D>), dim3(grid), dim3(512), 0, s, g)
+#define QA_PICK(MK, D)                                                                                     \
+    do {                                                                                                   \
+        if (S == 64) { if (f16) QA_LAUNCH(true, 64, MK, D); else QA_LAUNCH(false, 64, MK, D); }           \
+        else { if (f16) QA_LAUNCH(true, 32, MK, D); else QA_LAUNCH(false, 32, MK, D); }                   \
+    } while (0)
+    if (g.dbg) {                                                   // (tests: the q|k|v image is written out as well)
+        if (g.key_pad) QA_PICK(true, true); else QA_PICK(false, true);
     } else {
-        if (S == 64) { if (f16) QA_LAUNCH(true, 64, false); else QA_LAUNCH(false, 64, false); }
-        else { if (f16) QA_LAUNCH(true, 32, false); else QA_LAUNCH(false, 32, false); }
+        if (g.key_pad) QA_PICK(true, false); else QA_PICK(false, false);
     }
+#undef QA_PICK
 #undef QA_LAUNCH
     return launch_status("qkv_attn");
 }
 
 int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
-                  int B, int N, int dtype, float ln_eps, hipStream_t s) {
-    const QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, nullptr, B, N, B * N, ln_eps};
+                  const uint8_t* key_pad, int B, int N, int dtype, float ln_eps, hipStream_t s) {
+    const QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, nullptr, key_pad, B, N, B * N, ln_eps};
     return qkv_attention_launch(g, dtype, s);
 }
 
 }  // namespace bg
 
 extern "C" int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
-                               void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream) {
+                               const uint8_t* key_pad, void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps,
+                               bg_stream_t stream) {
     BG_REQUIRE(x_hi && w_qkv && out && B >= 0 && N >= 0, BG_E_ARG, "bg_qkv_attn_fwd: null pointer or negative size");
     BG_REQUIRE(bg::qkv_attn_eligible(B, N, dtype, stats_in, colsum, bias), BG_E_SHAPE,
                "bg_qkv_attn_fwd: needs 16-bit operands, an even N in [2, 64], LayerNorm-fold statistics / column sums / bias (16-byte aligned)");
     BG_REQUIRE(((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                ((uintptr_t)bias & 15) == 0 && ((uintptr_t)colsum & 15) == 0, BG_E_ALIGN, "bg_qkv_attn_fwd: 16-byte alignment");
-    bg::QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, B, N, B * N, ln_eps};
+    bg::QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, key_pad, B, N, B * N, ln_eps};
     return bg::qkv_attention_launch(g, dtype, (hipStream_t)stream);
 }

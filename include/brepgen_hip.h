@@ -139,11 +139,12 @@ int bg_attn_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N
 int bg_attn_varlen_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, int dtype,
                        const int* offsets, bg_stream_t stream);
 /* QKV projection with the LayerNorm fold + self-attention in ONE launch (csrc/qkv_attn.hip): sequences of an even length
- * N <= 64, all B of them equally long, no key-padding mask.  x_hi [B*N, 768] raw 16-bit rows, w_qkv [2304, 768] / bias / colsum as
- * bg_gemm_ex_fwd's fold operands, stats_in [12][B*N][2] the row statistics partials of x; out [B*N, 768] = what bg_gemm_ex_fwd
- * followed by bg_attn_fwd produce, bit for bit.  qkv_dbg (tests; may be NULL): [B*N, 2304] receives the q|k|v of that GEMM. */
+ * N <= 64, all B of them equally long; key_pad (may be NULL) as bg_attn_fwd's.  x_hi [B*N, 768] raw 16-bit rows, w_qkv [2304, 768] /
+ * bias / colsum as bg_gemm_ex_fwd's fold operands, stats_in [12][B*N][2] the row statistics partials of x; out [B*N, 768] = what
+ * bg_gemm_ex_fwd followed by bg_attn_fwd produce, bit for bit.  qkv_dbg (tests; may be NULL): [B*N, 2304] receives the q|k|v of
+ * that GEMM. */
 int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
-                    void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream);
+                    const uint8_t* key_pad, void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream);
 /* Valid-token compaction behind the variable-length execution (csrc/compact.hip): mask uint8 [B, n_mask] (1 = padded),
  * each entry covering `rep` consecutive tokens (EdgePosNet: one entry per face, rep = E).  Writes offsets int32 [B+1]
  * (offsets[B] = number of valid tokens; it stays on the device) and src_row int32 [B*n_mask*rep]: the padded-layout index of
@@ -392,7 +393,7 @@ int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number 
  *   key  8  split-residual launches on the 256 x 256 kernel: start delay of the second phase group, x 1024 cycles (< 0: none)
  *   key 10  256 x 256 persistent kernel: 1 = alone wherever eligible, 2 = never
  *   key 12  split-residual GEMMs of the encoder layers: 1 = the 128 x 128 persistent kernel instead of the pipelined one
- *   key 13  QKV + attention of short unmasked sequences: 1 = as two launches (GEMM, attention) instead of the fused kernel,
+ *   key 13  QKV + attention of short, equally long sequences: 1 = as two launches (GEMM, attention) instead of the fused kernel,
  *           2 = fused wherever eligible (the library's own choice also asks for enough tiles)
  *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off) */
 int bg_tune_set(int key, int value);

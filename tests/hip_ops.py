@@ -158,14 +158,18 @@ def encoder_layer(layer_weights, dtype, x, key_pad, B, N):
     return x
 
 
-def qkv_attention(x_hi, w_qkv, bias, colsum, stats_in, B, N, want_qkv=False, ln_eps=1e-5):
+def qkv_attention(x_hi, w_qkv, bias, colsum, stats_in, B, N, want_qkv=False, ln_eps=1e-5, key_pad=None):
     """bg_qkv_attn_fwd: LayerNorm-fold QKV + attention in one launch -> out [B*N, 768] (and the q|k|v image, want_qkv)."""
-    _need_cuda(x_hi, w_qkv, bias, colsum, stats_in)
+    _need_cuda(x_hi, w_qkv, bias, colsum, stats_in, key_pad)
     assert x_hi.shape == (B * N, 768) and w_qkv.shape == (2304, 768) and stats_in.shape == (12, B * N, 2)
     x_hi, w_qkv, stats_in = x_hi.contiguous(), w_qkv.contiguous(), stats_in.contiguous()
+    kp = None
+    if key_pad is not None:
+        kp = key_pad.contiguous()
+        kp = kp.view(torch.uint8) if kp.dtype == torch.bool else kp.to(torch.uint8)
     out = torch.empty(B * N, 768, device=x_hi.device, dtype=x_hi.dtype)
     dbg = torch.zeros(B * N, 2304, device=x_hi.device, dtype=x_hi.dtype) if want_qkv else None
-    check(_lib.load().bg_qkv_attn_fwd(ptr(x_hi), ptr(w_qkv), ptr(bias.contiguous()), ptr(colsum.contiguous()), ptr(stats_in),
+    check(_lib.load().bg_qkv_attn_fwd(ptr(x_hi), ptr(w_qkv), ptr(bias.contiguous()), ptr(colsum.contiguous()), ptr(stats_in), ptr(kp),
                                       ptr(out), ptr(dbg), B, N, bg_dtype(x_hi.dtype), ln_eps, stream()), "bg_qkv_attn_fwd")
     return (out, dbg) if want_qkv else out
 

@@ -81,7 +81,7 @@ def test_fused_qkv_attention_validates_before_launching():
     lib = _lib.load()
     fake = 0x10000
     f = lambda **kw: lib.bg_qkv_attn_fwd(kw.get("x", fake), fake, kw.get("bias", fake), kw.get("colsum", fake), kw.get("stats", fake),
-                                         fake, None, kw.get("B", 4), kw.get("N", 60), kw.get("dtype", _lib.BG_BF16), 1e-5, None)
+                                         None, fake, None, kw.get("B", 4), kw.get("N", 60), kw.get("dtype", _lib.BG_BF16), 1e-5, None)
     for kw in (dict(N=33), dict(N=66), dict(N=0), dict(dtype=_lib.BG_F32), dict(stats=None), dict(colsum=None), dict(bias=None),
                dict(stats=fake + 8)):
         assert f(**kw) == -2 and lib.bg_last_error(), kw                 # BG_E_SHAPE

@@ -215,11 +215,50 @@ def test_fused_qkv_attention_is_bit_identical_to_the_two_launches(pc, dt, B, N):
     assert torch.isfinite(ref.float()).all()
 
 
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,N", [(9, 60), (512, 60), (16, 30), (64, 64), (10, 34)])
+def test_fused_qkv_attention_with_a_key_padding_mask(pc, dt, B, N):
+    """The dense execution of a masked net (SurfZNet with varlen off): ragged key-padding masks, one sample with every key padded
+    (its outputs are 0 in both paths), one with none."""
+    import hip_ops as ops
+    a, w, b, cs, stats = _qkv_case(B, N, dt, B * 100 + N + 7)
+    g = torch.Generator().manual_seed(B + N)
+    nv = torch.randint(1, N + 1, (B,), generator=g)
+    nv[0], nv[-1] = 0, N
+    kp = (torch.arange(N)[None] >= nv[:, None]).cuda()
+    qkv = ops.linear_ex(a, w, b, stats_in=stats, colsum=cs)["out"]
+    ref = ops.attention(qkv, kp, B, N)
+    for _ in range(3):
+        out, img = ops.qkv_attention(a, w, b, cs, stats, B, N, want_qkv=True, key_pad=kp)
+        out2 = ops.qkv_attention(a, w, b, cs, stats, B, N, key_pad=kp)
+        torch.cuda.synchronize()
+        assert torch.equal(img, qkv)
+        assert torch.equal(out, ref) and torch.equal(out2, ref), (B, N, int((out.float() != ref.float()).sum()))
+    assert torch.isfinite(ref.float()).all() and float(ref[:N].float().abs().max()) == 0.0
+
+
 def test_fused_qkv_attention_rejects_what_it_does_not_cover(pc):
     import hip_ops as ops
     a, w, b, cs, stats = _qkv_case(4, 33, BF16, 1)                 # odd N: the statistics travel two rows per element
     with pytest.raises(RuntimeError):
         ops.qkv_attention(a, w, b, cs, stats, 4, 33)
+
+
+@pytest.mark.parametrize("n_split", [1, 2])
+def test_fused_qkv_attention_inside_the_densely_executed_masked_net(pc, tune, n_split):
+    """SurfZNet with variable-length execution off (every padded position computed, as the reference does): the fused launch takes
+    the key-padding mask; eps == eps of GEMM + attention, bit for bit."""
+    m, _ = pc.build_net("SurfZNet", 5, False, BF16, varlen=False)
+    m.n_split = n_split
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfZNet", 512, 60, 1, False)]
+    with torch.no_grad():
+        tune(13, 1)
+        ref = m(*args).clone()
+        tune(13, 0)
+        for _ in range(2):
+            got = m(*args)
+            torch.cuda.synchronize()
+            assert torch.isfinite(ref).all() and torch.equal(ref, got), n_split
 
 
 @pytest.mark.parametrize("dt", [BF16, F16])
