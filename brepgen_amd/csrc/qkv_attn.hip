@@ -471,10 +471,13 @@ bool qkv_attn_eligible(int B, int N, int dtype, const void* stats_in, const void
            (((size_t)stats_in) & 15) == 0 && (size_t)B * N * BG_D_MODEL * 2 < 0xffffffffull;
 }
 
-// One 256-slot tile per CU and round: below a round and a half of tiles the two-launch path (finer tiles) is the better fit.
+// One 256-slot tile per CU and round.  Measured against GEMM + attention (profiles/r04/qkv_attn_small_batches.log): the fused launch
+// wins from 24 tiles (16 samples x 30 tokens: 16 vs 25 us) through one full round (0.56-0.72) and again from a round and a half on
+// (0.68-0.83); only a second round that is less than about a third full is a wash (288 / 336 tiles: 1.03) -- left to the two launches.
 bool qkv_attn_worthwhile(int B, int N) {
     const int spt = N <= 32 ? 8 : 4;
-    return (B + spt - 1) / spt * BG_N_HEAD >= 384;
+    const int tiles = (B + spt - 1) / spt * BG_N_HEAD;
+    return tiles <= 256 || tiles >= 352;
 }
 
 int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {

@@ -24,6 +24,11 @@ def run(B=256, datalike=False, graphs=False):
     torch.manual_seed(0)
     dev = torch.device("cuda")
     nets = [cls(False).to(dev).eval() for cls in (bga.SurfPosNet, bga.SurfZNet, bga.EdgePosNet, bga.EdgeZNet)]
+    if os.environ.get("BG_SURFZ_VARLEN") in ("0", "1"):             # experiments: force SurfZNet's variable-length execution on / off
+        nets[1].varlen = os.environ["BG_SURFZ_VARLEN"] == "1"
+    for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):   # experiments: bg_tune_set key=value[,key=value]
+        from brepgen_amd import _lib
+        _lib.load().bg_tune_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     surf_vae = bga.AutoencoderKLFastDecode(**SURF_VAE_CFG).to(dev).eval()
     edge_vae = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).to(dev).eval()
     surf_vae.compute_dtype = edge_vae.compute_dtype = torch.bfloat16
