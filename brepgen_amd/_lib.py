@@ -99,6 +99,8 @@ _SIGNATURES = {
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_qkv_attn_fwd": (C.c_int, [vp, vp, fp, fp, fp, u8p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "bg_qkv_attn_paired_fwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "bg_compact_rows_paired": (C.c_int, [u8p, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "bg_attn_varlen_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "bg_compact_rows": (C.c_int, [u8p, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "bg_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -273,6 +273,13 @@ bool qkv_attn_worthwhile(int B, int N);      // enough (sample group, head) tile
 int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
                   const uint8_t* key_pad, int B, int N, int dtype, float ln_eps, hipStream_t s);
 
+int qkv_attention_paired(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
+                         void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats, int dtype, float ln_eps,
+                         hipStream_t s, double rows_hint);
+// slot-packed compaction (rep == 1, n_mask <= 64): 64-row slots of one or two whole samples; offsets [B + 1] (offsets[B] = rows),
+// src_row [64 B], slot_desc [2 B] (lengths of the samples of every slot), slot_a [B], counts [B] (scratch)
+int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a, int* counts,
+                        hipStream_t s, int* rule = nullptr);
 // valid-token compaction of a padded batch (csrc/compact.hip): mask [B, n_mask] uint8 (1 = padded), each mask entry
 // covering `rep` consecutive tokens (EdgePosNet: rep = E).  offsets [B+1] (offsets[B] = *m_dev = number of valid tokens),
 // src_row [B * n_mask * rep]: padded-layout index of every compact row, in order.

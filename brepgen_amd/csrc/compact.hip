@@ -87,6 +87,80 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const uint8_t* __restric
     }
 }
 
+// ---- slot-packed compaction (nets with <= 64 tokens per sample: the fused QKV + attention launch on ragged batches) ----------
+// Every 64-row slot holds one or two WHOLE samples: rows [0, n_a) sample a, [n_a, n_a + n_b) sample b, the rest clones of a's first
+// token (same src_row: every row-wise kernel computes the clone's bits exactly as the original's, the final scatter writes
+// identical values to the same place).  Lengths are sorted (rank = number of samples that are shorter, or equally long with a
+// smaller index: deterministic), then the shortest unpaired sample joins the longest one while their sum fits -- 0.96 of the slots
+// filled for lengths ~ U{8..60} against 0.69 with one sample per 32 / 64-slot.
+//   counts[b]          valid tokens of sample b (count_valid_kernel)
+//   offsets[b]         first row of sample b in the slot-packed layout (samples without a valid token: 0, never used)
+//   offsets[B]         = 64 * n_slots, the device-side row count every kernel reads
+//   slot_desc[2 k]     n_a, slot_desc[2 k + 1] n_b of slot k;   slot_a[k] = sample a of slot k
+__global__ __launch_bounds__(1024) void pair_slots_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
+                                                          int* __restrict__ slot_desc, int* __restrict__ slot_a, int* __restrict__ rule) {
+    extern __shared__ int sh[];                                   // [B] lengths, [B] sample ids in ascending length
+    int* len = sh;
+    int* sorted = sh + B;
+    __shared__ int n_slots_sh;
+    for (int i = threadIdx.x; i < B; i += 1024) len[i] = counts[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        const int li = len[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (len[j] < li) || (len[j] == li && j < i);
+        sorted[rank] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int i = 0, j = B - 1, k = 0;
+        while (i < B && len[sorted[i]] == 0) ++i;                 // samples without a valid token own no rows
+        while (i <= j) {
+            const int a = sorted[j], na = len[a];
+            int nb = 0;
+            if (i < j && len[sorted[i]] + na <= 64) {
+                const int b = sorted[i];
+                nb = len[b];
+                offsets[b] = 64 * k + na;
+                ++i;
+            }
+            offsets[a] = 64 * k;
+            slot_desc[2 * k] = na; slot_desc[2 * k + 1] = nb; slot_a[k] = a;
+            --j; ++k;
+        }
+        n_slots_sh = k;
+        offsets[B] = 64 * k;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 1024)
+        if (len[i] == 0) offsets[i] = 0;
+    if (rule != nullptr && threadIdx.x < P256_RULE_ENTRIES) {
+        const int nt = threadIdx.x >> 2 == 0 ? 3 : (threadIdx.x >> 2 == 1 ? 4 : 9);
+        rule[threadIdx.x] = p256_rows(64 * n_slots_sh, nt, (threadIdx.x & 2) != 0, (threadIdx.x & 1) != 0);
+    }
+}
+
+// the rows of a slot behind its two samples: clones of the slot's first row (src_row[64 k] is sample a's first valid token)
+__global__ __launch_bounds__(64) void fill_clones_kernel(const int* __restrict__ offsets_B, const int* __restrict__ slot_desc,
+                                                         int* __restrict__ src_row) {
+    const int k = blockIdx.x;
+    if (64 * k >= *offsets_B) return;
+    const int used = slot_desc[2 * k] + slot_desc[2 * k + 1];
+    const int t = threadIdx.x;
+    if (t >= used) src_row[64 * k + t] = src_row[64 * k];
+}
+
+// (rep == 1, n_mask <= 64.)  offsets [B + 1], src_row [64 B], slot_desc [2 B], slot_a [B]
+int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a,
+                        int* counts, hipStream_t s, int* rule) {
+    ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * 6.0, s);
+    hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, counts);
+    hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), (size_t)2 * B * sizeof(int), s, counts, B, offsets, slot_desc, slot_a, rule);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, offsets, src_row);
+    hipLaunchKernelGGL(fill_clones_kernel, dim3(B), dim3(64), 0, s, offsets + B, slot_desc, src_row);
+    return launch_status("compact_rows_paired");
+}
+
 int compact_rows(const uint8_t* mask, int B, int n_mask, int rep, int* offsets, int* src_row, hipStream_t s, int* rule) {
     ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * (2.0 + 4.0 * rep), s);
     // counts live in src_row's tail?  no: keep it simple -- offsets[1..B] doubles as the count buffer before the scan
@@ -102,4 +176,11 @@ extern "C" int bg_compact_rows(const uint8_t* mask, int B, int n_mask, int rep, 
     BG_REQUIRE(mask && offsets && src_row, BG_E_ARG, "bg_compact_rows: null pointer");
     BG_REQUIRE(B > 0 && n_mask > 0 && rep > 0, BG_E_SHAPE, "bg_compact_rows: empty shape");
     return bg::compact_rows(mask, B, n_mask, rep, offsets, src_row, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int bg_compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a,
+                                      int* counts, bg_stream_t stream) {
+    BG_REQUIRE(mask && offsets && src_row && slot_desc && slot_a && counts, BG_E_ARG, "bg_compact_rows_paired: null pointer");
+    BG_REQUIRE(B > 0 && B <= 8192 && n_mask > 0 && n_mask <= 64, BG_E_SHAPE, "bg_compact_rows_paired: 1 .. 8192 samples of 1 .. 64 tokens");
+    return bg::compact_rows_paired(mask, B, n_mask, offsets, src_row, slot_desc, slot_a, counts, (hipStream_t)stream, nullptr);
 }

@@ -63,24 +63,36 @@ __global__ void expand_mask_kernel(const uint8_t* __restrict__ in, uint8_t* __re
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, off_rows, total;
+    size_t off_x, off_h, off_r, off_small, off_f, off_mask, off_stats, off_rows, off_slots, total;
     int M, F;
+    int Mrow;           // row capacity of the token buffers: M, or 64 rows per sample where a ragged batch may run slot-packed
 };
+
+// Slot-packed variable-length execution (compact.hip: compact_rows_paired + the fused QKV / attention launch): nets whose samples
+// have at most 64 tokens, 16-bit modes.  Its rows are 64-row slots of one or two samples -- up to 64 B of them, more than the
+// padded batch when nothing can be paired -- so the token buffers of these nets are planned for 64 rows per sample.
+static inline bool slot_packing_applies(int net, int B, int S, int E, int dtype) {
+    return net == BG_SURFZ && E == 1 && S <= 64 && dtype != BG_F32 && B <= 8192;
+}
 
 static Workspace plan(int net, int B, int S, int E, int dtype) {
     Workspace w{};
     const size_t es = (dtype == BG_F32) ? 4 : 2;
     w.M = B * S * E;
     w.F = B * S;
+    const bool slots = slot_packing_applies(net, B, S, E, dtype);
+    w.Mrow = slots && 64 * B > w.M ? 64 * B : w.M;
+    const size_t Fr = slots ? (size_t)w.Mrow : (size_t)w.F;        // (the per-face conditioning embed of SurfZNet runs on the compact rows)
     size_t o = 0;
-    w.off_x = o; o += align_up((size_t)w.M * 768 * 4);
-    w.off_h = o; o += align_up((size_t)w.M * 768 * es);
-    w.off_r = o; o += align_up((size_t)w.M * 2304 * es);
+    w.off_x = o; o += align_up((size_t)w.Mrow * 768 * 4);
+    w.off_h = o; o += align_up((size_t)w.Mrow * 768 * es);
+    w.off_r = o; o += align_up((size_t)w.Mrow * 2304 * es);
     w.off_small = o; o += align_up((size_t)(4 * B + B) * 768 * 4);      // sincos, t0, t1(as fp32 worst case), temb, cvec
-    w.off_f = o; o += (net != BG_SURFPOS) ? align_up((size_t)w.F * 768 * 4) : 0;
+    w.off_f = o; o += (net != BG_SURFPOS) ? align_up(Fr * 768 * 4) : 0;
     w.off_mask = o; o += (net == BG_EDGEPOS) ? align_up((size_t)w.M) : 0;
-    w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.M * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
-    w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2 + P256_RULE_ENTRIES) * 4) + align_up((size_t)w.M * 4) : 0;   // var-len: offsets + GEMM partition table, row map
+    w.off_stats = o; o += (dtype != BG_F32) ? align_up((size_t)w.Mrow * 12 * 2 * 4) : 0;   // LayerNorm-fold row partials
+    w.off_rows = o; o += (net != BG_SURFPOS) ? align_up((size_t)(B + 2 + P256_RULE_ENTRIES) * 4) + align_up((size_t)w.Mrow * 4) : 0;   // var-len: offsets + GEMM partition table, row map
+    w.off_slots = o; o += slots ? align_up((size_t)4 * B * 4) : 0;       // slot-packed: (n_a, n_b) per slot, first sample per slot, counts
     w.total = o;
     return w;
 }
@@ -106,6 +118,7 @@ struct Ctx {
     const int* src_row = nullptr;     // compact row -> padded-layout token index
     const int* offsets = nullptr;     // per-sample first row, [B+1]
     const int* rule = nullptr;        // 256 / 128 kernel partition of the GEMM launches for this row count (compact.hip)
+    const int* slot_desc = nullptr;   // slot-packed batch: (n_a, n_b) per 64-row slot (compact_rows_paired)
     int N_tok = 1;                    // tokens per sample of the padded layout
     double rows_hint = 0.0, pairs_hint = 0.0;   // host-side estimates: GEMM kernel choice + profiler accounting (brepgen_hip.h)
     int concurrent = 0;               // sibling sample groups are in flight on forked streams (n_split > 1)
@@ -183,7 +196,14 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     c.X = reinterpret_cast<float*>(c.ws + c.p.off_x);
     c.H = c.ws + c.p.off_h;
     c.R = c.ws + c.p.off_r;
-    const int M = c.p.M, F = c.p.F, N = S * E, nt = in->n_timesteps;
+    const int Mpad = c.p.M, F = c.p.F, N = S * E, nt = in->n_timesteps;
+    // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
+    const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
+    // ragged batches of short sequences: slot-packed rows + the fused QKV / attention launch (bg_tune key 13 = 1: dense packing +
+    // GEMM + attention, the bit-equality baseline)
+    const bool paired = varlen && slot_packing_applies(net, B, S, E, w->dtype) && w->n_layer > 0 && w->layers[0].qkv_colsum != nullptr &&
+                        g_tune[TUNE_QKV_ATTN] != 1;
+    const int M = paired ? c.p.Mrow : Mpad;                       // row bound of every token-wise launch
     c.fold = w->dtype != BG_F32 && w->n_layer > 0 && w->layers[0].qkv_colsum != nullptr;
     if (c.fold) {
         for (int li = 0; li < w->n_layer; ++li)
@@ -193,21 +213,26 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         c.XL = reinterpret_cast<unsigned char*>(c.X) + (size_t)M * 768 * 2;
         c.stats = reinterpret_cast<float*>(c.ws + c.p.off_stats);
     }
-    // ---- variable-length execution: compact the valid tokens (row count stays on the device) ----------------------
-    const bool varlen = in->varlen != 0 && in->mask != nullptr && net != BG_SURFPOS;
     c.N_tok = N;
     c.concurrent = concurrent ? 1 : 0;
     if (varlen) {
         int* offs = reinterpret_cast<int*>(c.ws + c.p.off_rows);
         int* srow = reinterpret_cast<int*>(c.ws + c.p.off_rows + align_up((size_t)(B + 2 + P256_RULE_ENTRIES) * 4));
         const int n_mask = (net == BG_EDGEPOS) ? S : N, rep = (net == BG_EDGEPOS) ? E : 1;
-        int rcc = compact_rows(in->mask, B, n_mask, rep, offs, srow, s, offs + B + 2);
+        int rcc;
+        if (paired) {
+            int* sd = reinterpret_cast<int*>(c.ws + c.p.off_slots);
+            rcc = compact_rows_paired(in->mask, B, n_mask, offs, srow, sd, sd + 2 * B, sd + 3 * B, s, offs + B + 2);
+            c.slot_desc = sd;
+        } else {
+            rcc = compact_rows(in->mask, B, n_mask, rep, offs, srow, s, offs + B + 2);
+        }
         if (rcc) return rcc;
         c.offsets = offs; c.m_dev = offs + B; c.src_row = srow; c.rule = offs + B + 2;
         c.rows_hint = in->rows_hint > 0 ? in->rows_hint : 0.0;
         c.pairs_hint = in->pairs_hint > 0 ? in->pairs_hint : 0.0;
         // padded positions of the result are defined as 0 (the valid rows are scattered over this)
-        const hipError_t he = hipMemsetAsync(eps_out, 0, (size_t)M * w->fc_out.n_out * sizeof(float), s);
+        const hipError_t he = hipMemsetAsync(eps_out, 0, (size_t)Mpad * w->fc_out.n_out * sizeof(float), s);
         BG_REQUIRE(he == hipSuccess, (int)he, "bg_denoiser_fwd: hipMemsetAsync failed: %s", hipGetErrorString(he));
     }
     float* small = reinterpret_cast<float*>(c.ws + c.p.off_small);
@@ -232,7 +257,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         if (!(in->cond_cache && in->cond_cache_valid)) {
             if (net == BG_SURFZ && fcond_compact) {
                 // faces == tokens: without a cache to fill, only the valid faces need their conditioning embed
-                if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1, false, true, true))) return rc;
+                if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, paired ? M : F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1, false, true, true))) return rc;
             } else if (net == BG_SURFZ) {
                 if ((rc = embed_mlp(c, w->embed[1], in->surf_pos, 6, F, fcond, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
             } else {
@@ -275,6 +300,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
 
     // ---- 12 pre-LN encoder layers ---------------------------------------------------------------------------
+    BG_REQUIRE(!paired || c.fold, BG_E_ARG, "bg_denoiser_fwd: slot-packed execution needs the LayerNorm-fold operands");
     const bool fused_qkv = c.fold && !varlen && g_tune[TUNE_QKV_ATTN] != 1 &&
                            qkv_attn_eligible(B, N, c.dtype, c.stats, w->layers[0].qkv_colsum, w->layers[0].b_qkv) &&
                            (g_tune[TUNE_QKV_ATTN] == 2 || qkv_attn_worthwhile(B, N));
@@ -284,7 +310,11 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
         qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
-        if (fused_qkv) {
+        if (paired) {
+            // ragged batch, slot-packed: one or two whole samples per 64-row slot (qkv_attn.hip, PAIR)
+            if ((rc = qkv_attention_paired(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, nullptr, c.m_dev, c.slot_desc, B, M, c.dtype,
+                                           1e-5f, s, c.rows_hint))) return rc;
+        } else if (fused_qkv) {
             // short, equally long sequences (SurfPosNet; SurfZNet executed densely): q|k|v never leave the CU (qkv_attn.hip; bit-identical)
             if ((rc = qkv_attention(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, key_pad, B, N, c.dtype, 1e-5f, s))) return rc;
         } else {

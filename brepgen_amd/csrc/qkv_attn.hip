@@ -69,6 +69,10 @@ struct QkvAttnArgs {
     const uint8_t* key_pad;   // optional [B, N]: 1 = padded key (dense execution of a masked net); queries are computed at every position
     int B, N, M;
     float ln_eps;
+    // slot-packed ragged batch (compact.hip: compact_rows_paired): rows = 64-row slots of one or two whole samples, *m_dev of them
+    // exist (a multiple of 64), slot_desc[2 k] / [2 k + 1] = the lengths of slot k's samples; B is then the slot bound, N = 64
+    const int* m_dev = nullptr;
+    const int* slot_desc = nullptr;
 };
 
 __device__ __forceinline__ int qa_opaque(int x) {
@@ -76,7 +80,7 @@ __device__ __forceinline__ int qa_opaque(int x) {
     return x;
 }
 
-template <bool F16, int S, bool MASK, bool DBG = false>
+template <bool F16, int S, bool MASK, bool DBG = false, bool PAIR = false>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     using E = Elem<F16>;
     using T = typename E::T;
@@ -93,7 +97,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     // stores in the epilogue), the other wn = 1 (half of k + v: the transposing 16-bit stores)
     const int wm = wave >> 1, wn = (wave ^ (wave >> 2)) & 1;
     const int late = wave >> 2;               // waves 4-7 (rows 128-255) run one barrier behind
-    const int n_groups = (g.B + SPT - 1) / SPT;
+    static_assert(!PAIR || (S == 64 && !MASK), "slot-packed batches: 64-row slots, dead keys come from the slot descriptors");
+    const int Mv = PAIR ? *g.m_dev : 0;                           // slot-packed batch: rows present (device-side count, a multiple of 64)
+    const int n_groups = PAIR ? (Mv + 255) >> 8 : (g.B + SPT - 1) / SPT;
     const int T_all = n_groups * BG_N_HEAD;
     const int G = gridDim.x;
     int L = xcd_remap(blockIdx.x, G);
@@ -128,6 +134,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     auto piece_row = [&](int ln, int r) { return (wave + 8 * r) * 8 + (ln >> 3); };
     auto piece_chunk = [&](int ln, int r) { return (unsigned)(((ln & 7) ^ ((piece_row(ln, r) >> 1) & 7)) * 16); };
     auto slot_row = [&](int grp, int tile_row) {                  // global token of a tile row (slots past a sample's end: its last token)
+        if (PAIR) {                                               // slot-packed batch: the tile's rows are consecutive global rows
+            const int row = grp * 256 + tile_row;
+            return row < Mv ? row : Mv - 1;
+        }
         int smp = grp * SPT + tile_row / S;
         smp = smp < g.B ? smp : g.B - 1;
         int tok = tile_row % S;
@@ -242,6 +252,11 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if (PAIR) {
+        // a sub-tile of a slot's second sample reads up to 60 V^T elements past its row -- the next row, the next slot, or, behind the
+        // last image, LDS nobody writes: stale bits there may be inf / NaN patterns, and 0 * inf is NaN
+        if (threadIdx.x < 32) reinterpret_cast<unsigned*>(lds + QA_VIMG + 4 * 64 * VS * 2)[threadIdx.x] = 0u;
+    }
     // ---- prologue of the first tile: buffer 0 complete, A of buffer 1 in flight (as if issued in phase 6) ----
     a_offsets(grp);
     stage_stats(grp); stage_cols(head);
@@ -304,6 +319,15 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         // ---------------- epilogue ----------------
         const int ln = qa_opaque(threadIdx.x & 63), l31 = ln & 31, hq = ln >> 5;
         T* dbg = reinterpret_cast<T*>(g.dbg);
+        // slot-packed batch: the lengths of the two samples of this wave's slot (rows 64 wm ..: the wave's GEMM rows AND its queries)
+        int pair_na = 64, pair_nb = 0;
+        if (PAIR) {
+            const int gslot = grp * 4 + wm;
+            if (gslot * 64 < Mv) { pair_na = g.slot_desc[2 * gslot]; pair_nb = g.slot_desc[2 * gslot + 1]; }
+            pair_na = __builtin_amdgcn_readfirstlane(pair_na);
+            pair_nb = __builtin_amdgcn_readfirstlane(pair_nb);
+        }
+        const int pair_ob = (pair_na + 3) & ~3;
         float key_bias = 0.f;                                    // (MASK) slot threadIdx.x of the tile: requested now, written to LDS after the images
         if (MASK && threadIdx.x < 256) {
             const int smp = grp * SPT + (int)threadIdx.x / S, key = (int)threadIdx.x % S;
@@ -334,6 +358,22 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                     const int R = wm * 64 + i * 32 + l31;         // token slot of the tile
                     if (c3 < 2) {
                         *reinterpret_cast<uint2*>(lds + QA_QIMG + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
+                    } else if (PAIR) {
+                        // slot row t -> V^T column: sample a's keys at [0, n_a), everything behind (sample b, then the clones) from the
+                        // 4-aligned column ob on; the <= 3 columns between and the columns behind the last row are filled with a
+                        // neighbour's (finite) value -- they are read as dead keys with p = 0
+                        const int t = R & 63, col = t < pair_na ? t : pair_ob + (t - pair_na);
+                        T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + wm * (64 * VS);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vt[(d + e) * VS + col] = pk.t[e];
+                        if (t == pair_na - 1)
+                            for (int cc = pair_na; cc < pair_ob; ++cc)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) vt[(d + e) * VS + cc] = pk.t[e];
+                        if (t == 63)
+                            for (int cc = col + 1; cc < VS; ++cc)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) vt[(d + e) * VS + cc] = pk.t[e];
                     } else {
                         T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + (R / S) * (64 * VS) + (R % S);
 #pragma unroll
@@ -341,8 +381,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                     }
                     if (DBG) {
                         const int smp = grp * SPT + R / S, tok = R % S;
-                        if (smp < g.B && tok < g.N)
-                            *reinterpret_cast<uint2*>(dbg + (size_t)(smp * g.N + tok) * (3 * LD) + c3 * LD + head * 64 + d) = pk.u;
+                        if (PAIR ? grp * 256 + R < Mv : (smp < g.B && tok < g.N))
+                            *reinterpret_cast<uint2*>(dbg + (size_t)(PAIR ? grp * 256 + R : smp * g.N + tok) * (3 * LD) + c3 * LD + head * 64 + d) = pk.u;
                     }
                 }
             }
@@ -353,11 +393,14 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         if (has_next) stage_cols(head_n);                        // bias / column sums of the next tile travel while the attention runs
 
         // ---- attention: 32 queries of one sample per wave (attn16_kernel, attn.hip) ----
+        // Slot-packed batch: the slot holds two samples; each is walked in sub-tiles of 32 keys FROM ITS OWN first key, exactly as
+        // attn16_kernel walks a compacted sample.  A lane that does not belong to the block's sample sees -inf scores: its running
+        // maximum stays, alpha = exp(0) = 1, p = 0 -- the update is an exact no-op, so every lane ends with attn16_kernel's bits.
         {
             const int wq = wm * 2 + wn;                            // (a bijection of the waves; wm = the sample's row block)
             const int slot = wq / WPS, qb = wq % WPS;
             const int smp = grp * SPT + slot;
-            if (smp < g.B) {
+            if (PAIR ? (grp * 256 + slot * 64 < Mv) : (smp < g.B)) {
                 const int h = hq;
                 const unsigned char* qimg = lds + QA_QIMG + (slot * S + qb * 32) * 128;
                 const unsigned char* ktile = lds + QA_KIMG + slot * S * 128;
@@ -372,78 +415,96 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
                 float m_run = -INFINITY, l_run = 0.f;
+                const int tq = qb * 32 + l31;                     // the lane's query row inside its slot
+                const bool in_b = PAIR && tq >= pair_na && tq < pair_na + pair_nb;   // (the clones behind both samples belong to a)
+                bool first = true;                                // uniform: no score block has been executed yet
 #pragma unroll
-                for (int sub = 0; sub < WPS; ++sub) {
-                    if (sub * 32 >= g.N) break;                   // uniform: sub-tile entirely past the last key
-                    f32x16 s;
+                for (int si = 0; si < (PAIR ? 2 : 1); ++si) {
+                    const int cnt = PAIR ? (si == 0 ? pair_na : pair_nb) : g.N;
+                    const int row0 = (PAIR && si == 1) ? pair_na : 0;        // the sample's first key row inside the slot ...
+                    const int col0 = (PAIR && si == 1) ? pair_ob : 0;        // ... and its first V^T column
+                    const bool member = !PAIR || (in_b == (si == 1));
+                    if (PAIR && __ballot(member) == 0ull) continue;          // uniform: none of the wave's queries is in this sample
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                    for (int sub = 0; sub < WPS; ++sub) {
+                        if (sub * 32 >= cnt) break;               // uniform: sub-tile entirely past the last key
+                        f32x16 s;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const V8 kf = *reinterpret_cast<const V8*>(ktile + (sub * 32 + l31) * 128 + (((ks * 2 + h) ^ sw) << 4));
-                        s = E::mfma(kf, qf[ks], s);
-                    }
-                    // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query l31
-                    // (attn16_kernel adds a 0 / -inf bias to every score; adding 0 changes nothing the softmax can see, so only a
-                    //  sub-tile that holds keys past the sample's end pays for it)
-                    if (MASK) {                                   // the sample's padded keys (and the slots past its end): attn16_kernel's mb
-                        const float* mb = reinterpret_cast<const float*>(lds + QA_MB) + slot * S + sub * 32 + 4 * h;
+                        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                        int kr = row0 + sub * 32 + l31;           // key row inside the slot (slot-packed: never past the slot)
+                        if (PAIR) kr = kr < 63 ? kr : 63;
+                        const int ksw = PAIR ? (kr >> 1) & 7 : sw;
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const float4 mbv = *reinterpret_cast<const float4*>(mb + 8 * g4);
-                            s[4 * g4 + 0] += mbv.x; s[4 * g4 + 1] += mbv.y; s[4 * g4 + 2] += mbv.z; s[4 * g4 + 3] += mbv.w;
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const V8 kf = *reinterpret_cast<const V8*>(ktile + kr * 128 + (((ks * 2 + h) ^ ksw) << 4));
+                            s = E::mfma(kf, qf[ks], s);
                         }
-                    } else if (sub * 32 + 32 > g.N) {
-                        const int thr = g.N - sub * 32 - 4 * h;       // register r is dead iff (r&3) + 8 (r>>2) >= thr
+                        // register r <-> key sub*32 + (r&3) + 8*(r>>2) + 4*h of query l31
+                        // (attn16_kernel adds a 0 / -inf bias to every score; adding 0 changes nothing the softmax can see, so only a
+                        //  sub-tile that holds keys past the sample's end pays for it)
+                        if (MASK) {                               // the sample's padded keys (and the slots past its end): attn16_kernel's mb
+                            const float* mb = reinterpret_cast<const float*>(lds + QA_MB) + slot * S + sub * 32 + 4 * h;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) s[r] += ((r & 3) + 8 * (r >> 2)) >= thr ? -INFINITY : 0.f;
-                    }
-                    float mloc = -INFINITY;
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const float4 mbv = *reinterpret_cast<const float4*>(mb + 8 * g4);
+                                s[4 * g4 + 0] += mbv.x; s[4 * g4 + 1] += mbv.y; s[4 * g4 + 2] += mbv.z; s[4 * g4 + 3] += mbv.w;
+                            }
+                        } else if (PAIR) {
+                            const int thr = member ? cnt - sub * 32 - 4 * h : -64;   // dead: keys past the sample's end; every key for a lane of the other sample
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        mloc = fmaxf(mloc, fmaxf(fmaxf(s[4 * g4 + 0], s[4 * g4 + 1]), fmaxf(s[4 * g4 + 2], s[4 * g4 + 3])));
-                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                    const float m_new = fmaxf(m_run, mloc);
-                    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                    float psum = 0.f;
+                            for (int r = 0; r < 16; ++r) s[r] += ((r & 3) + 8 * (r >> 2)) >= thr ? -INFINITY : 0.f;
+                        } else if (sub * 32 + 32 > g.N) {
+                            const int thr = g.N - sub * 32 - 4 * h;   // register r is dead iff (r&3) + 8 (r>>2) >= thr
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        s[r] = __expf(s[r] - m_use);
-                        psum += s[r];
-                    }
-                    if (sub == 0) {                               // (running sum and O are 0: their rescaling by alpha = 0 leaves 0)
-                        l_run = psum;
-                    } else {
-                        const float alpha = __expf(m_run - m_use);
-                        l_run = l_run * alpha + psum;
+                            for (int r = 0; r < 16; ++r) s[r] += ((r & 3) + 8 * (r >> 2)) >= thr ? -INFINITY : 0.f;
+                        }
+                        float mloc = -INFINITY;
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt)
+                        for (int g4 = 0; g4 < 4; ++g4)
+                            mloc = fmaxf(mloc, fmaxf(fmaxf(s[4 * g4 + 0], s[4 * g4 + 1]), fmaxf(s[4 * g4 + 2], s[4 * g4 + 3])));
+                        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                        const float m_new = fmaxf(m_run, mloc);
+                        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                        float psum = 0.f;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                    }
-                    m_run = m_new;
+                        for (int r = 0; r < 16; ++r) {
+                            s[r] = __expf(s[r] - m_use);
+                            psum += s[r];
+                        }
+                        if (first) {                              // (running sum and O are 0: their rescaling by alpha = 0 leaves 0)
+                            l_run = psum;
+                        } else {
+                            const float alpha = __expf(m_run - m_use);
+                            l_run = l_run * alpha + psum;
 #pragma unroll
-                    for (int sl = 0; sl < 2; ++sl) {
-                        V8 pb;
+                            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) pb[e] = (T)s[8 * sl + e];
+                                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                        }
+                        first = false;
+                        m_run = m_new;
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            const T* vrow = vt + (dt * 32 + l31) * VS + sub * 32 + 16 * sl + 4 * h;
-                            const V4 lo = *reinterpret_cast<const V4*>(vrow);
-                            const V4 hi = *reinterpret_cast<const V4*>(vrow + 8);
-                            V8 va;
-                            va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
-                            va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
-                            o[dt] = E::mfma(va, pb, o[dt]);
+                        for (int sl = 0; sl < 2; ++sl) {
+                            V8 pb;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pb[e] = (T)s[8 * sl + e];
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt) {
+                                const T* vrow = vt + (dt * 32 + l31) * VS + col0 + sub * 32 + 16 * sl + 4 * h;
+                                const V4 lo = *reinterpret_cast<const V4*>(vrow);
+                                const V4 hi = *reinterpret_cast<const V4*>(vrow + 8);
+                                V8 va;
+                                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+                                va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                                o[dt] = E::mfma(va, pb, o[dt]);
+                            }
                         }
                     }
                 }
                 const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
                 const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-                const int qi = qb * 32 + l31;
-                if (qi < g.N) {
-                    T* op = reinterpret_cast<T*>(g.out) + (size_t)(smp * g.N + qi) * LD + head * 64;
+                if (PAIR || tq < g.N) {
+                    T* op = reinterpret_cast<T*>(g.out) + (size_t)(PAIR ? grp * 256 + slot * 64 + tq : smp * g.N + tq) * LD + head * 64;
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -505,6 +566,30 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
     return launch_status("qkv_attn");
 }
 
+// slot-packed ragged batch (compact.hip: compact_rows_paired): *m_dev rows in 64-row slots of one or two samples, at most
+// `slot_bound` slots; m_stats = the row stride of the statistics partials (the workspace's row capacity)
+int qkv_attention_paired(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
+                         void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats, int dtype, float ln_eps,
+                         hipStream_t s, double rows_hint) {
+    if (slot_bound <= 0) return 0;
+    QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, nullptr, slot_bound, 64, m_stats, ln_eps};
+    g.m_dev = m_dev;
+    g.slot_desc = slot_desc;
+    const int tiles = (slot_bound + 3) / 4 * BG_N_HEAD;           // upper bound: the kernel reads the row count on the device
+    const double rows = rows_hint > 0 ? rows_hint : 64.0 * slot_bound;
+    ProfScope prof(PK_QKV_ATTN, 2.0 * rows * BG_D_MODEL * 3 * BG_D_MODEL + 4.0 * BG_N_HEAD * rows * 34.0 * BG_D_HEAD,
+                   rows * (2.0 * BG_D_MODEL * 2 + FOLD_PARTS * 8.0) + 2.0 * 3 * BG_D_MODEL * BG_D_MODEL + 2 * 4.0 * 3 * BG_D_MODEL, s);
+    const int grid = tiles < 256 ? tiles : 256;
+    if (dtype == BG_F16) {
+        if (qkv_dbg) hipLaunchKernelGGL((qkv_attn_kernel<true, 64, false, true, true>), dim3(grid), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((qkv_attn_kernel<true, 64, false, false, true>), dim3(grid), dim3(512), 0, s, g);
+    } else {
+        if (qkv_dbg) hipLaunchKernelGGL((qkv_attn_kernel<false, 64, false, true, true>), dim3(grid), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((qkv_attn_kernel<false, 64, false, false, true>), dim3(grid), dim3(512), 0, s, g);
+    }
+    return launch_status("qkv_attn_paired");
+}
+
 int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
                   const uint8_t* key_pad, int B, int N, int dtype, float ln_eps, hipStream_t s) {
     const QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, nullptr, key_pad, B, N, B * N, ln_eps};
@@ -523,4 +608,17 @@ extern "C" int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float*
                ((uintptr_t)bias & 15) == 0 && ((uintptr_t)colsum & 15) == 0, BG_E_ALIGN, "bg_qkv_attn_fwd: 16-byte alignment");
     bg::QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, key_pad, B, N, B * N, ln_eps};
     return bg::qkv_attention_launch(g, dtype, (hipStream_t)stream);
+}
+
+extern "C" int bg_qkv_attn_paired_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
+                                      void* out, void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats,
+                                      int dtype, float ln_eps, bg_stream_t stream) {
+    BG_REQUIRE(x_hi && w_qkv && out && m_dev && slot_desc && slot_bound > 0 && m_stats >= 64 * slot_bound, BG_E_ARG,
+               "bg_qkv_attn_paired_fwd: null pointer, or a statistics stride below 64 rows per slot");
+    BG_REQUIRE((dtype == BG_BF16 || dtype == BG_F16) && stats_in && colsum && bias && (m_stats & 1) == 0, BG_E_SHAPE,
+               "bg_qkv_attn_paired_fwd: 16-bit operands with LayerNorm-fold statistics / column sums / bias");
+    BG_REQUIRE(((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
+               ((uintptr_t)colsum & 15) == 0 && ((uintptr_t)stats_in & 15) == 0, BG_E_ALIGN, "bg_qkv_attn_paired_fwd: 16-byte alignment");
+    return bg::qkv_attention_paired(x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, m_dev, slot_desc, slot_bound, m_stats, dtype, ln_eps,
+                                    (hipStream_t)stream, 0.0);
 }

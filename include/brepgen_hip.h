@@ -145,6 +145,18 @@ int bg_attn_varlen_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B
  * that GEMM. */
 int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
                     const uint8_t* key_pad, void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream);
+/* The same launch on a SLOT-PACKED ragged batch (bg_compact_rows_paired): *m_dev rows (device-side, a multiple of 64) in 64-row
+ * slots of one or two whole samples, slot_desc[2 k] / [2 k + 1] their lengths, at most slot_bound slots; m_stats = row stride of
+ * stats_in.  out rows = what bg_gemm_ex_fwd + bg_attn_varlen_fwd produce for the same samples on the dense packing, bit for bit. */
+int bg_qkv_attn_paired_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
+                           void* out, void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats,
+                           int dtype, float ln_eps, bg_stream_t stream);
+/* Slot-packed compaction for samples of at most 64 tokens (mask [B, n_mask], 1 = padded): every 64-row slot holds one or two whole
+ * samples (shortest joins longest while the sum fits), the rows behind them are clones of the slot's first row.  offsets [B + 1]:
+ * first row of every sample, offsets[B] = 64 * slots (stays on the device); src_row [64 B]; slot_desc [2 B]; slot_a [B]: the first
+ * sample of every slot; counts [B]: scratch. */
+int bg_compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a,
+                           int* counts, bg_stream_t stream);
 /* Valid-token compaction behind the variable-length execution (csrc/compact.hip): mask uint8 [B, n_mask] (1 = padded),
  * each entry covering `rep` consecutive tokens (EdgePosNet: one entry per face, rep = E).  Writes offsets int32 [B+1]
  * (offsets[B] = number of valid tokens; it stays on the device) and src_row int32 [B*n_mask*rep]: the padded-layout index of

@@ -277,3 +277,148 @@ def test_fused_qkv_attention_inside_the_denoiser(pc, tune, dt, B, S, n_split):
             got = m(*args)
             torch.cuda.synchronize()
             assert torch.isfinite(ref).all() and torch.equal(ref, got), (B, S, n_split)
+
+
+# ---- ragged batches through the fused launch: slot-packed compaction (csrc/compact.hip) + the PAIR variant of qkv_attn.hip ------
+def _pair_slots_reference(n):
+    """The pairing of compact.hip: pair_slots_kernel, restated: ascending (length, index); the shortest unpaired sample joins the
+    longest one while their sum fits 64; samples without a valid token own no rows."""
+    B = len(n)
+    order = sorted(range(B), key=lambda i: (n[i], i))
+    i, j, slots, start = 0, B - 1, [], [0] * B
+    while i < B and n[order[i]] == 0:
+        i += 1
+    while i <= j:
+        a, na, b, nb = order[j], n[order[j]], -1, 0
+        if i < j and n[order[i]] + na <= 64:
+            b, nb = order[i], n[order[i]]
+            start[b] = 64 * len(slots) + na
+            i += 1
+        start[a] = 64 * len(slots)
+        slots.append((a, na, b, nb))
+        j -= 1
+    return slots, start
+
+
+def _ragged_lengths(B, N, seed, lo=0):
+    g = torch.Generator().manual_seed(seed)
+    n = torch.randint(lo, N + 1, (B,), generator=g)
+    n[0], n[-1] = N, max(lo, 1)
+    return n
+
+
+@pytest.mark.parametrize("B,N", [(512, 60), (37, 64), (5, 8), (300, 30)])
+def test_slot_packed_compaction_matches_its_restatement(pc, B, N):
+    from brepgen_amd import _lib
+    n = _ragged_lengths(B, N, B + N)
+    mask = (torch.arange(N)[None] >= n[:, None])
+    perm_mask = mask.clone()
+    for b in range(B):                                            # valid tokens anywhere in the row, not only at its front
+        perm_mask[b] = mask[b][torch.randperm(N, generator=torch.Generator().manual_seed(b))]
+    m_dev = perm_mask.to(torch.uint8).cuda()
+    offs = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    src = torch.full((64 * B,), -1, dtype=torch.int32, device="cuda")
+    sd = torch.zeros(2 * B, dtype=torch.int32, device="cuda")
+    sa = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().bg_compact_rows_paired(m_dev.data_ptr(), B, N, offs.data_ptr(), src.data_ptr(), sd.data_ptr(), sa.data_ptr(),
+                                                  cnt.data_ptr(), _lib.stream()), "bg_compact_rows_paired")
+    torch.cuda.synchronize()
+    slots, start = _pair_slots_reference(n.tolist())
+    assert int(offs[B]) == 64 * len(slots)
+    assert cnt.cpu().tolist() == n.tolist()
+    sdc, sac, offc, srcc = sd.cpu().tolist(), sa.cpu().tolist(), offs.cpu().tolist(), src.cpu().tolist()
+    for k, (a, na, b, nb) in enumerate(slots):
+        assert (sdc[2 * k], sdc[2 * k + 1], sac[k]) == (na, nb, a), k
+        valid_a = [a * N + i for i in range(N) if not perm_mask[a, i]]
+        rows = valid_a + ([b * N + i for i in range(N) if not perm_mask[b, i]] if b >= 0 else [])
+        rows += [valid_a[0]] * (64 - len(rows))                   # clones of the slot's first token
+        assert srcc[64 * k:64 * k + 64] == rows, k
+    for b in range(B):
+        if n[b] > 0:
+            assert offc[b] == start[b], b
+    fill = sum(n.tolist()) / max(1, 64 * len(slots))
+    _record(f"slot_packing_fill_B{B}_N{N}", round(fill, 4))
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,N,lo", [(512, 60, 8), (64, 64, 1), (9, 60, 1), (130, 30, 0)])
+def test_fused_qkv_attention_on_a_slot_packed_ragged_batch(pc, dt, B, N, lo):
+    """The rows of a ragged batch, dense-packed through bg_gemm_ex_fwd (LayerNorm fold) + bg_attn_varlen_fwd, against the same samples
+    slot-packed (two per 64-row slot where they fit) through the fused launch: every valid token's output bit for bit, and the clone
+    rows of a slot equal to the row they clone."""
+    import hip_ops as ops
+    from brepgen_amd import _lib
+    lib = _lib.load()
+    n = _ragged_lengths(B, N, 3 * B + N, lo).tolist()
+    slots, start = _pair_slots_reference(n)
+    off = [0]
+    for v in n:
+        off.append(off[-1] + v)
+    Md, Ms = off[-1], 64 * len(slots)
+    g = torch.Generator().manual_seed(B * 7 + N)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    x = rn(Md, 768) * 2                                           # the valid tokens, dense-packed
+    w = rn(2304, 768) * 0.04
+    w[:768] *= 0.125
+    w, b = w.to(dt).cuda(), rn(2304).cuda()
+    cs = w.float().sum(1).contiguous()
+
+    def stats_of(rows):
+        grp = rows.reshape(rows.shape[0], 12, 64)
+        return torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().cuda()
+
+    # dense packing: two launches
+    Mpad_d = Md + (Md & 1)                                        # (the fold launches take an even row count)
+    xd = torch.cat([x, x[-1:]]) if Md & 1 else x
+    qkv = ops.linear_ex(xd.to(dt).cuda(), w, b, stats_in=stats_of(xd), colsum=cs)["out"][:Md].contiguous()
+    ref = torch.empty(Md, 768, device="cuda", dtype=dt)
+    offs_d = torch.tensor(off, dtype=torch.int32, device="cuda")
+    _lib.check(lib.bg_attn_varlen_fwd(qkv.data_ptr(), None, ref.data_ptr(), B, N, _lib.BG_F16 if dt == F16 else _lib.BG_BF16,
+                                      offs_d.data_ptr(), _lib.stream()), "bg_attn_varlen_fwd")
+    # slot packing
+    src = []
+    for (a, na, bb, nb) in slots:
+        rows = list(range(off[a], off[a] + na)) + (list(range(off[bb], off[bb] + nb)) if bb >= 0 else [])
+        src += rows + [off[a]] * (64 - len(rows))
+    src_t = torch.tensor(src, dtype=torch.long)
+    xs = x[src_t]
+    cap = Ms + 128                                                # row capacity beyond the rows present (the kernel reads the count on the device)
+    xs_dev = torch.zeros(cap, 768, dtype=dt, device="cuda")
+    xs_dev[:Ms] = xs.to(dt).cuda()
+    st = torch.zeros(12, cap, 2, device="cuda")
+    st[:, :Ms] = stats_of(xs)
+    sd = torch.tensor([v for (_, na, _, nb) in slots for v in (na, nb)] + [0, 0] * 2, dtype=torch.int32, device="cuda")
+    m_dev = torch.tensor([Ms], dtype=torch.int32, device="cuda")
+    for rep in range(3):
+        out = torch.zeros(cap, 768, device="cuda", dtype=dt)
+        img = torch.zeros(cap, 2304, device="cuda", dtype=dt)
+        _lib.check(lib.bg_qkv_attn_paired_fwd(xs_dev.data_ptr(), w.data_ptr(), b.data_ptr(), cs.data_ptr(), st.data_ptr(), out.data_ptr(),
+                                              img.data_ptr(), m_dev.data_ptr(), sd.data_ptr(), len(slots) + 2, cap,
+                                              _lib.BG_F16 if dt == F16 else _lib.BG_BF16, 1e-5, _lib.stream()), "bg_qkv_attn_paired_fwd")
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        assert torch.equal(img[:Ms], qkv[src_t.cuda()]), int((img[:Ms].float() != qkv[src_t.cuda()].float()).sum())
+        got, want = out[:Ms], ref[src_t.cuda()]
+        bad = (got.float() != want.float()).any(1)
+        assert not bad.any(), (B, N, int(bad.sum()), bad.nonzero()[:8].flatten().tolist())
+        assert float(out[Ms:].float().abs().max()) == 0.0          # nothing written past the rows present
+
+
+@pytest.mark.parametrize("n_split", [1, 2])
+@pytest.mark.parametrize("dt", [BF16, F16])
+def test_slot_packed_execution_inside_the_denoiser(pc, tune, dt, n_split):
+    """SurfZNet at the headline shape (512 x 60, ragged mask), variable-length execution: slot-packed rows + the fused launch against
+    the dense packing + GEMM + attention (key 13 = 1): eps bit for bit, zeros at the padded positions."""
+    m, _ = pc.build_net("SurfZNet", 5, False, dt, varlen=True)
+    m.n_split = n_split
+    args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfZNet", 512, 60, 1, False)]
+    with torch.no_grad():
+        tune(13, 1)
+        ref = m(*args).clone()
+        tune(13, 0)
+        for _ in range(2):
+            got = m(*args)
+            torch.cuda.synchronize()
+            assert torch.isfinite(ref).all() and torch.equal(ref, got), n_split
+    assert float(ref[args[3]].abs().max()) == 0.0
