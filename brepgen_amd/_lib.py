@@ -151,7 +151,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export the ABI
             fn.restype, fn.argtypes = res, args
-        if lib.bg_abi_version() != 4:
+        if lib.bg_abi_version() != 5:
             raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
         for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):     # A/B knobs, e.g. BG_TUNE="0=10,5=1"
             k, v = kv.split("=")

@@ -34,10 +34,11 @@ def _digest():
     h.update(" ".join(FLAGS).encode())
     # the compiler is part of the build: the kernels that run at the 256-VGPR limit (gemm_p256.hip, gemm_split.hip) are checked for
     # spills with THIS hipcc (tests/test_abi_cpu.py); another version has to rebuild -- and re-run that check
+    # (no hipcc on this box: the digest then covers the sources only -- see build())
     try:
         h.update(subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.encode())
-    except OSError:
-        pass
+    except (OSError, RuntimeError):
+        return None
     return h.hexdigest()
 
 
@@ -55,6 +56,12 @@ def build(force=False, save_temps=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     stamp = os.path.join(OBJ, "digest.txt")
     dig = _digest()
+    if dig is None:
+        # a box without a compiler: the prebuilt library that travelled with the tree is what there is (its digest cannot be
+        # re-derived without hipcc's version string); without it there is nothing to load -- fail loudly
+        if os.path.exists(LIB) and not force:
+            return LIB
+        _hipcc()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     extra = ["-save-temps"] if save_temps else []

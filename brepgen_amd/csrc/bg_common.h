@@ -275,7 +275,7 @@ int qkv_attention(const void* x_hi, const void* w_qkv, const float* bias, const 
 
 int qkv_attention_paired(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
                          void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats, int dtype, float ln_eps,
-                         hipStream_t s, double rows_hint);
+                         hipStream_t s, double rows_hint, double pairs_hint);
 // slot-packed compaction (rep == 1, n_mask <= 64): 64-row slots of one or two whole samples; offsets [B + 1] (offsets[B] = rows),
 // src_row [64 B], slot_desc [2 B] (lengths of the samples of every slot), slot_a [B], counts [B] (scratch)
 int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a, int* counts,

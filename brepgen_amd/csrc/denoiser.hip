@@ -81,7 +81,10 @@ static Workspace plan(int net, int B, int S, int E, int dtype) {
     w.M = B * S * E;
     w.F = B * S;
     const bool slots = slot_packing_applies(net, B, S, E, dtype);
-    w.Mrow = slots && 64 * B > w.M ? 64 * B : w.M;
+    // worst case of the slot-packed layout: S <= 32 -- any two samples fit one slot, at most ceil(B / 2) slots; otherwise nothing
+    // may pair: one slot per sample
+    const int slot_rows = 64 * (S <= 32 ? (B + 1) / 2 : B);
+    w.Mrow = slots && slot_rows > w.M ? slot_rows : w.M;
     const size_t Fr = slots ? (size_t)w.Mrow : (size_t)w.F;        // (the per-face conditioning embed of SurfZNet runs on the compact rows)
     size_t o = 0;
     w.off_x = o; o += align_up((size_t)w.Mrow * 768 * 4);
@@ -312,8 +315,9 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
         if (paired) {
             // ragged batch, slot-packed: one or two whole samples per 64-row slot (qkv_attn.hip, PAIR)
-            if ((rc = qkv_attention_paired(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, nullptr, c.m_dev, c.slot_desc, B, M, c.dtype,
-                                           1e-5f, s, c.rows_hint))) return rc;
+            if ((rc = qkv_attention_paired(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, nullptr, c.m_dev, c.slot_desc,
+                                           B < (M + 63) / 64 ? B : (M + 63) / 64, M, c.dtype,
+                                           1e-5f, s, c.rows_hint, c.pairs_hint))) return rc;
         } else if (fused_qkv) {
             // short, equally long sequences (SurfPosNet; SurfZNet executed densely): q|k|v never leave the CU (qkv_attn.hip; bit-identical)
             if ((rc = qkv_attention(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, key_pad, B, N, c.dtype, 1e-5f, s))) return rc;

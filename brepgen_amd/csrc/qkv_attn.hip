@@ -577,14 +577,17 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
 // `slot_bound` slots; m_stats = the row stride of the statistics partials (the workspace's row capacity)
 int qkv_attention_paired(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in, void* out,
                          void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats, int dtype, float ln_eps,
-                         hipStream_t s, double rows_hint) {
+                         hipStream_t s, double rows_hint, double pairs_hint) {
     if (slot_bound <= 0) return 0;
     QkvAttnArgs g{x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, nullptr, slot_bound, 64, m_stats, ln_eps};
     g.m_dev = m_dev;
     g.slot_desc = slot_desc;
     const int tiles = (slot_bound + 3) / 4 * BG_N_HEAD;           // upper bound: the kernel reads the row count on the device
+    // (opt-in profiler only: executed rows and attention pairs = sum over the samples of n^2, from the caller's host-side estimates;
+    //  without them the slot bound -- every slot full, one sample of 64 tokens each)
     const double rows = rows_hint > 0 ? rows_hint : 64.0 * slot_bound;
-    ProfScope prof(PK_QKV_ATTN, 2.0 * rows * BG_D_MODEL * 3 * BG_D_MODEL + 4.0 * BG_N_HEAD * rows * 34.0 * BG_D_HEAD,
+    const double pairs = pairs_hint > 0 ? pairs_hint : 64.0 * rows;
+    ProfScope prof(PK_QKV_ATTN, 2.0 * rows * BG_D_MODEL * 3 * BG_D_MODEL + 4.0 * BG_N_HEAD * pairs * BG_D_HEAD,
                    rows * (2.0 * BG_D_MODEL * 2 + FOLD_PARTS * 8.0) + 2.0 * 3 * BG_D_MODEL * BG_D_MODEL + 2 * 4.0 * 3 * BG_D_MODEL, s);
     const int grid = tiles < 256 ? tiles : 256;
     if (dtype == BG_F16) {
@@ -626,6 +629,8 @@ extern "C" int bg_qkv_attn_paired_fwd(const void* x_hi, const void* w_qkv, const
                "bg_qkv_attn_paired_fwd: 16-bit operands with LayerNorm-fold statistics / column sums / bias");
     BG_REQUIRE(((uintptr_t)x_hi & 15) == 0 && ((uintptr_t)w_qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)bias & 15) == 0 &&
                ((uintptr_t)colsum & 15) == 0 && ((uintptr_t)stats_in & 15) == 0, BG_E_ALIGN, "bg_qkv_attn_paired_fwd: 16-byte alignment");
+    // (the kernel forms 32-bit byte offsets row * 1536 over the slot rows)
+    BG_REQUIRE((size_t)64 * slot_bound * BG_D_MODEL * 2 < 0xffffffffull, BG_E_SHAPE, "bg_qkv_attn_paired_fwd: more than 43 690 slots");
     return bg::qkv_attention_paired(x_hi, w_qkv, bias, colsum, stats_in, out, qkv_dbg, m_dev, slot_desc, slot_bound, m_stats, dtype, ln_eps,
-                                    (hipStream_t)stream, 0.0);
+                                    (hipStream_t)stream, 0.0, 0.0);
 }

@@ -236,10 +236,10 @@ class _HipDenoiser(nn.Module):
     def _row_hints(self, mask, S, E):
         """(valid tokens, sum over samples of valid^2) of this mask -- the host-side ESTIMATE bg_denoiser_fwd takes (GEMM kernel
         choice + profiler accounting; the kernels count the rows themselves).  Never a host synchronisation: a mask seen for the
-        first time is counted asynchronously (a few tiny kernels + a copy into pinned memory behind an event) and this call passes
-        0 = unknown; calls with the same mask tensor use the count once the event has fired.  A caller that builds a fresh mask
-        tensor every step (sample.py:197, 216: `mask.repeat(2, ...)`) therefore always runs with the estimate 0 -- correct, and
-        bit-identical to the run with the estimate."""
+        first time is only remembered; the second call with the same tensor starts an asynchronous count (a few tiny kernels + a
+        copy into pinned memory behind an event) and still passes 0 = unknown; later calls use the count once the event has fired.
+        A caller that builds a fresh mask tensor every step (sample.py:197, 216: `mask.repeat(2, ...)`) therefore always runs with
+        the estimate 0 -- correct, bit-identical to the run with the estimate, and at no cost."""
         if self.profile_hints:
             return self.profile_hints
         if torch.cuda.is_current_stream_capturing():
@@ -247,6 +247,12 @@ class _HipDenoiser(nn.Module):
         key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
         hc = self._hint_cache
         if hc.get("key") != key:
+            # first sight of this mask: remember it, count nothing -- a caller that builds a fresh mask tensor every step pays no
+            # launch and no pinned allocation for an estimate it would never get to use
+            self._hint_cache = {"key": key, "event": None, "hints": None, "keep": mask}
+            return 0.0, 0.0
+        if hc["event"] is None:
+            # second call with the same tensor: the count is worth starting
             valid = (~mask.reshape(mask.shape[0], -1).bool()).sum(1).double()
             if self.NET == BG_EDGEPOS:                     # the mask marks faces, every valid face carries E edge tokens
                 valid = valid * E
@@ -255,7 +261,7 @@ class _HipDenoiser(nn.Module):
             ev = torch.cuda.Event()
             ev.record()
             # (the entry keeps the mask alive: its storage cannot be recycled for another mask while it is the key)
-            self._hint_cache = {"key": key, "host": host, "event": ev, "hints": None, "keep": mask}
+            hc["host"], hc["event"] = host, ev
             return 0.0, 0.0
         if hc["hints"] is None:
             if not hc["event"].query():

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 4
+#define BG_ABI_VERSION 5
 
 typedef void* bg_stream_t;              /* hipStream_t */
 
@@ -147,7 +147,10 @@ int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, cons
                     const uint8_t* key_pad, void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream);
 /* The same launch on a SLOT-PACKED ragged batch (bg_compact_rows_paired): *m_dev rows (device-side, a multiple of 64) in 64-row
  * slots of one or two whole samples, slot_desc[2 k] / [2 k + 1] their lengths, at most slot_bound slots; m_stats = row stride of
- * stats_in.  out rows = what bg_gemm_ex_fwd + bg_attn_varlen_fwd produce for the same samples on the dense packing, bit for bit. */
+ * stats_in.  out rows = what bg_gemm_ex_fwd + bg_attn_varlen_fwd produce for the same samples on the dense packing, bit for bit.
+ * Invariants the kernel TRUSTS (bg_compact_rows_paired guarantees them; nothing on the device re-checks): *m_dev <= 64 * slot_bound
+ * and a multiple of 64; slot_desc[2 k] >= 1, slot_desc[2 k] + slot_desc[2 k + 1] <= 64 for every slot below *m_dev / 64;
+ * slot_bound <= 43 690 (32-bit row offsets; rejected above). */
 int bg_qkv_attn_paired_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
                            void* out, void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats,
                            int dtype, float ln_eps, bg_stream_t stream);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/brepgen_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.bg_abi_version() == 4
+    assert lib.bg_abi_version() == 5
 
 
 def test_argument_errors_are_negative_and_explained():

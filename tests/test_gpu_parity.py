@@ -182,6 +182,11 @@ def test_layernorm_split_input(pc, dtype):
     assert e["finite"] and e["max_abs"] < (3e-2 if dtype == BF16 else 4e-3)
 
 
+# bf16 eps against the fp32 oracle on the small seeded cases below: 2 x the largest value the MI355X measured on them
+# (0.8-1.5e-2, gpurun_out/parity_r05.json -> profiles/r05/; the per-case golden bounds further down are per case)
+BF16_EPS_BOUND = 3e-2
+
+
 def test_fold_and_unfolded_paths_agree(pc):
     """fold_layernorm=False keeps the fp32 residual stream and the LayerNorm kernels; both must sit within the same
     distance of the oracle."""
@@ -194,8 +199,24 @@ def test_fold_and_unfolded_paths_agree(pc):
         m.fold_layernorm = False
         plain = m(*cu).cpu()
     valid = ~args[3]
-    assert float((folded - want)[valid].abs().max()) < 4e-2 and float((plain - want)[valid].abs().max()) < 4e-2
-    assert float((folded - plain)[valid].abs().max()) < 4e-2 and not torch.equal(folded, plain)
+    ef, ep, efp = (float((a - b)[valid].abs().max()) for a, b in ((folded, want), (plain, want), (folded, plain)))
+    _record("fold_vs_unfolded_surfz_b4_bf16", folded_vs_oracle=ef, plain_vs_oracle=ep, folded_vs_plain=efp)
+    assert ef < BF16_EPS_BOUND and ep < BF16_EPS_BOUND and efp < BF16_EPS_BOUND and not torch.equal(folded, plain)
+
+
+def _record(key, **vals):
+    """Measured parity numbers of this run -> gpurun_out/parity_r05.json (copied to profiles/ by hand: the bounds below are 2 x them)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r05.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    d[key] = vals
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
 
 
 # ---- whole denoisers ----------------------------------------------------------------------------------
@@ -221,18 +242,8 @@ GOLDEN_BF16_BOUND = {"_default": (4e-2, 8e-3),
 
 @pytest.mark.parametrize("name", GOLDEN)
 def test_denoiser_bf16_vs_reference_golden(pc, name):
-    import json
     e = pc.golden_case(name, BF16)
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r04.json")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
-        d = {}
-    d["golden_bf16_" + name] = {"max_abs_valid": e["max_abs_valid"], "mean_abs": e["mean_abs"], "ref_absmax": e["ref_absmax"]}
-    with open(path, "w") as f:
-        json.dump(d, f, indent=1, sort_keys=True)
+    _record("golden_bf16_" + name, max_abs_valid=e["max_abs_valid"], mean_abs=e["mean_abs"], ref_absmax=e["ref_absmax"])
     bmax, bmean = GOLDEN_BF16_BOUND.get(name, GOLDEN_BF16_BOUND["_default"])
     assert e["finite"] and e["max_abs_valid"] < bmax and e["mean_abs"] < bmean, e
 
@@ -240,8 +251,10 @@ def test_denoiser_bf16_vs_reference_golden(pc, name):
 def test_denoiser_vs_oracle_larger(pc):
     assert pc.oracle_case("SurfZNet", 4, 60, 1, F32)["max_abs"] < 1e-5
     assert pc.oracle_case("SurfPosNet", 5, 30, 1, F32, use_cf=True)["max_abs"] < 1e-5
-    assert pc.oracle_case("EdgeZNet", 1, 10, 20, BF16)["max_abs_valid"] < 4e-2
-    assert pc.oracle_case("EdgePosNet", 2, 8, 20, BF16, use_cf=True)["max_abs_valid"] < 4e-2
+    ez = pc.oracle_case("EdgeZNet", 1, 10, 20, BF16)["max_abs_valid"]
+    ep = pc.oracle_case("EdgePosNet", 2, 8, 20, BF16, use_cf=True)["max_abs_valid"]
+    _record("oracle_larger_bf16", edgez_b1_s10_e20=ez, edgepos_cf_b2_s8_e20=ep)
+    assert ez < BF16_EPS_BOUND and ep < BF16_EPS_BOUND
 
 
 def test_baseline_config0_ddpm_chain(pc):
@@ -252,9 +265,11 @@ def test_baseline_config0_ddpm_chain(pc):
     # bf16 operands: eps carries ~1.5e-2 (8 mantissa bits through 12 layers); with the 50-step schedule eps enters
     # x_{t-1} with a coefficient of up to ~0.3, with the sampling schedule (1000 steps, sample.py:144) ~0.007-0.02
     e = pc.ddpm_chain_case(BF16, steps=50)
-    assert e["finite"] and e["max_abs_eps"] < 4e-2 and e["max_abs_x"] < 1.2e-2
+    _record("ddpm_chain_bf16_50_steps", **e)
+    assert e["finite"] and e["max_abs_eps"] < BF16_EPS_BOUND and e["max_abs_x"] < 1.2e-2
     e = pc.ddpm_chain_case(BF16, steps=1000, last=12)
-    assert e["finite"] and e["max_abs_eps"] < 4e-2 and e["max_abs_x"] < 1e-3     # north_star: 1e-3 bf16 per step
+    _record("ddpm_chain_bf16_last_12_of_1000", **e)
+    assert e["finite"] and e["max_abs_eps"] < BF16_EPS_BOUND and e["max_abs_x"] < 1e-3     # north_star: 1e-3 bf16 per step
 
 
 def test_conditioning_cache_and_masked_rows(pc):

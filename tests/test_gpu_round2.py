@@ -232,7 +232,7 @@ def test_varlen_fp32_vs_reference_golden(pc, name):
 
 def test_varlen_vs_oracle_and_single_valid_token(pc):
     e = pc.oracle_case("EdgeZNet", 1, 10, 20, BF16, varlen=True)
-    assert e["max_abs_valid"] < 4e-2 and e["padded_absmax"] == 0.0
+    assert e["max_abs_valid"] < 3e-2 and e["padded_absmax"] == 0.0      # 2 x measured (test_gpu_parity.BF16_EPS_BOUND)
     e = pc.oracle_case("EdgePosNet", 2, 8, 20, F32, use_cf=True, varlen=True)
     assert e["max_abs_valid"] < 1e-5 and e["padded_absmax"] == 0.0
     # one sample with a single valid face, one with all faces valid
