@@ -7,7 +7,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 WHAT=${1:-all}
-PMC_STEPS=40; PMC_WARMUP=3        # the step mix bench.py's roofline.traffic is compared against (tools/pmc_summary.py <round> 40 3)
+PMC_STEPS=20; PMC_WARMUP=5        # the driver's own step mix (python bench.py --steps 20 --warmup 5): tools/pmc_summary.py <round> 20 5
 if [[ $WHAT == all || $WHAT == test ]]; then
   timeout 1300 python -m pytest tests -m gpu -q --durations=25 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
