@@ -20,7 +20,7 @@ vp, fp, i64p, u8p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device po
 class MlpWeights(C.Structure):
     _fields_ = [("w0", vp), ("b0", fp), ("ln_g", fp), ("ln_b", fp), ("w3", vp), ("b3", fp),
                 ("k_in", C.c_int), ("n_out", C.c_int), ("n_out_pad", C.c_int), ("w0_dtype", C.c_int),
-                ("w0_mfma", fp)]
+                ("w0_mfma", fp), ("w0_colsum", fp)]
 
 
 class LayerWeights(C.Structure):
@@ -36,7 +36,7 @@ class DenoiserWeights(C.Structure):
                 ("lnf_g", fp), ("lnf_b", fp),
                 ("time_embed", MlpWeights), ("fc_out", MlpWeights),
                 ("embed", MlpWeights * BG_MAX_EMBEDS),
-                ("class_embed", fp)]
+                ("class_embed", fp), ("time_table", fp), ("time_table_rows", C.c_int), ("_pad3", C.c_int)]
 
 
 class DenoiserInputs(C.Structure):
@@ -97,6 +97,7 @@ _SIGNATURES = {
                              C.c_size_t, vp]),
     "bg_layernorm_split_fwd": (C.c_int, [vp, vp, fp, fp, vp, C.c_int, C.c_int, C.c_float, vp]),
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
+    "bg_ln_silu_out_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_qkv_attn_fwd": (C.c_int, [vp, vp, fp, fp, fp, u8p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_qkv_attn_paired_fwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),

@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_OUT_TAIL, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -288,6 +288,14 @@ int sincos_embed(const int64_t* t, int n, float* out, hipStream_t s);
 // c[b,:] = temb[(nt==1?0:b),:] + (class_embed ? class_embed[label[b],:] : 0)
 int cond_vector(const float* temb, int nt, const float* class_embed, const int64_t* label, float* c, int B,
                 hipStream_t s);
+// same with temb[b] = table[timesteps[(nt == 1 ? 0 : b)]] looked up in a precomputed [table_rows, 768] time-embedding table
+// (a timestep outside the table gives NaN rows: fails loudly in the result)
+int cond_vector_table(const float* table, int table_rows, const int64_t* timesteps, int nt, const float* class_embed,
+                      const int64_t* label, float* c, int B, hipStream_t s);
+// eps = W3 . SiLU(LayerNorm(t0)) + b3 in one launch (out_tail.hip): t0 [M, 768] 16-bit, out fp32 [*, n_out]
+bool ln_silu_out_supported(int n_out, int n_out_pad);
+int ln_silu_out(const void* t0, const float* gam, const float* bet, const void* w3, const float* b3, float* out, int n_out, int n_out_pad,
+                int M, int dtype, float eps, hipStream_t s, const int* m_dev = nullptr, const int* row_map = nullptr, double rows_hint = 0.0);
 // out = f32 -> bf16 cast (n elements, n % 4 == 0)
 int cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
 

@@ -99,44 +99,64 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const uint8_t* __restric
 //   slot_desc[2 k]     n_a, slot_desc[2 k + 1] n_b of slot k;   slot_a[k] = sample a of slot k
 __global__ __launch_bounds__(1024) void pair_slots_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
                                                           int* __restrict__ slot_desc, int* __restrict__ slot_a, int* __restrict__ rule) {
-    extern __shared__ int sh[];                                   // [B] lengths, [B] sample ids in ascending length
-    int* len = sh;
-    int* sorted = sh + B;
+    // [B] sample ids in ascending length, [B] slot -> rank of its second sample (or -1), [B] lengths, [B] lengths in ascending order
+    extern __shared__ unsigned char sh[];
+    short* sorted = reinterpret_cast<short*>(sh);
+    short* pair_i = sorted + B;
+    unsigned char* len = reinterpret_cast<unsigned char*>(pair_i + B);
+    unsigned char* slen = len + B;
     __shared__ int n_slots_sh;
-    for (int i = threadIdx.x; i < B; i += 1024) len[i] = counts[i];
+    for (int i = threadIdx.x; i < B; i += 1024) len[i] = (unsigned char)counts[i];
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 1024) {
         const int li = len[i];
         int rank = 0;
         for (int j = 0; j < B; ++j) rank += (len[j] < li) || (len[j] == li && j < i);
-        sorted[rank] = i;
+        sorted[rank] = (short)i;
+        slen[rank] = (unsigned char)li;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // the two-pointer walk is inherently serial, so it touches nothing but LDS and keeps the next length of either pointer
+        // loaded ahead of its use (slot k always takes rank B - 1 - k as its first sample); everything else is written out by all
+        // threads below.  (Round 4 walked it with global stores and dependent LDS reads in every iteration: 63 us at B = 512.)
         int i = 0, j = B - 1, k = 0;
-        while (i < B && len[sorted[i]] == 0) ++i;                 // samples without a valid token own no rows
+        while (i < B && slen[i] == 0) ++i;                        // samples without a valid token own no rows
+        int li = i < B ? slen[i] : 0, li_next = i + 1 < B ? slen[i + 1] : 0;
+        int lj = j >= 0 ? slen[j] : 0, lj_next = j >= 1 ? slen[j - 1] : 0;
         while (i <= j) {
-            const int a = sorted[j], na = len[a];
-            int nb = 0;
-            if (i < j && len[sorted[i]] + na <= 64) {
-                const int b = sorted[i];
-                nb = len[b];
-                offsets[b] = 64 * k + na;
+            const bool paired = i < j && li + lj <= 64;
+            pair_i[k] = paired ? (short)i : (short)-1;
+            if (paired) {
                 ++i;
+                li = li_next;
+                li_next = i + 1 < B ? slen[i + 1] : 0;
             }
-            offsets[a] = 64 * k;
-            slot_desc[2 * k] = na; slot_desc[2 * k + 1] = nb; slot_a[k] = a;
             --j; ++k;
+            lj = lj_next;
+            lj_next = j >= 1 ? slen[j - 1] : 0;
         }
         n_slots_sh = k;
         offsets[B] = 64 * k;
     }
     __syncthreads();
+    const int n_slots = n_slots_sh;
+    for (int k = threadIdx.x; k < n_slots; k += 1024) {
+        const int a = sorted[B - 1 - k], na = len[a];
+        int nb = 0;
+        if (pair_i[k] >= 0) {
+            const int b = sorted[pair_i[k]];
+            nb = len[b];
+            offsets[b] = 64 * k + na;
+        }
+        offsets[a] = 64 * k;
+        slot_desc[2 * k] = na; slot_desc[2 * k + 1] = nb; slot_a[k] = a;
+    }
     for (int i = threadIdx.x; i < B; i += 1024)
         if (len[i] == 0) offsets[i] = 0;
     if (rule != nullptr && threadIdx.x < P256_RULE_ENTRIES) {
         const int nt = threadIdx.x >> 2 == 0 ? 3 : (threadIdx.x >> 2 == 1 ? 4 : 9);
-        rule[threadIdx.x] = p256_rows(64 * n_slots_sh, nt, (threadIdx.x & 2) != 0, (threadIdx.x & 1) != 0);
+        rule[threadIdx.x] = p256_rows(64 * n_slots, nt, (threadIdx.x & 2) != 0, (threadIdx.x & 1) != 0);
     }
 }
 
@@ -155,7 +175,7 @@ int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, in
                         int* counts, hipStream_t s, int* rule) {
     ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * 6.0, s);
     hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, counts);
-    hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), (size_t)2 * B * sizeof(int), s, counts, B, offsets, slot_desc, slot_a, rule);
+    hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), (size_t)6 * B, s, counts, B, offsets, slot_desc, slot_a, rule);
     hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, offsets, src_row);
     hipLaunchKernelGGL(fill_clones_kernel, dim3(B), dim3(64), 0, s, offsets + B, slot_desc, src_row);
     return launch_status("compact_rows_paired");

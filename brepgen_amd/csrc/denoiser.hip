@@ -37,7 +37,7 @@ bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(generic: 128x64 / 64x64 tiles)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
                                           "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
                                           "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)",
-                                          "qkv_attn_kernel(256x192 + attention)"};
+                                          "qkv_attn_kernel(256x192 + attention)", "ln_silu_out_kernel"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {
@@ -245,9 +245,14 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     int rc;
 
     // ---- time (+class) embedding -> one vector per sample --------------------------------------------------
-    if ((rc = sincos_embed(in->timesteps, nt, sc, s))) return rc;
-    if ((rc = embed_mlp(c, w->time_embed, sc, 768, nt, temb, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
-    if ((rc = cond_vector(temb, nt, w->class_embed, in->class_label, cvec, B, s))) return rc;
+    if (w->time_table != nullptr && w->time_table_rows > 0) {
+        // the time-embedding MLP is a function of the weights and the timestep only: looked up in the table the caller precomputed
+        if ((rc = cond_vector_table(w->time_table, w->time_table_rows, in->timesteps, nt, w->class_embed, in->class_label, cvec, B, s))) return rc;
+    } else {
+        if ((rc = sincos_embed(in->timesteps, nt, sc, s))) return rc;
+        if ((rc = embed_mlp(c, w->time_embed, sc, 768, nt, temb, 768, nullptr, 0, 1, nullptr, 0, 1))) return rc;
+        if ((rc = cond_vector(temb, nt, w->class_embed, in->class_label, cvec, B, s))) return rc;
+    }
 
     // ---- token embeddings -> X [M,768] fp32 ----------------------------------------------------------------
     // step-invariant part (per face): SurfZ: p_embed(surfPos); Edge nets: surfp_embed(surfPos)+surfz_embed(surfZ)
@@ -359,15 +364,29 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
     }
 
     // ---- final LayerNorm + fc_out ---------------------------------------------------------------------------
+    const bg_mlp_weights& mo = w->fc_out;
+    if (mo.w0_colsum != nullptr) {
+        BG_REQUIRE(c.fold && mo.w0_dtype == c.dtype && ln_silu_out_supported(mo.n_out, mo.n_out_pad), BG_E_ARG,
+                   "bg_denoiser_fwd: fc_out carries the folded final LayerNorm (w0_colsum): needs the 16-bit LayerNorm-fold layers and n_out <= 48");
+        // 16-bit modes: the final LayerNorm is folded into fc_out.0 (the epilogue of QKV / FFN1: raw XH rows in, the statistics the
+        // last FFN2 left behind), and LayerNorm + SiLU + Linear(768, n_out) are one launch (out_tail.hip) -- two launches, and the
+        // [M, 768] intermediate crosses HBM once, in 16 bits
+        GemmArgs g0{c.XH, 768, mo.w0, mo.b0, c.H, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
+        g0.stats_in = c.stats; g0.colsum = mo.w0_colsum;
+        g0.m_dev = c.m_dev; g0.rule_table = c.rule; g0.rows_hint = c.rows_hint; g0.concurrent = c.concurrent;
+        if ((rc = gemm(g0, c.dtype, s))) return rc;
+        // (variable-length: the compact result rows are scattered into the zero-filled padded eps_out)
+        return ln_silu_out(c.H, mo.ln_g, mo.ln_b, mo.w3, mo.b3, eps_out, mo.n_out, mo.n_out_pad, M, c.dtype, 1e-5f, s, c.m_dev,
+                           varlen ? c.src_row : nullptr, c.rows_hint);
+    }
     // fc_out.0 reads the final-LN output from H and writes its fp32 result to R; the LN+SiLU then overwrites H.
     {
         void* hf = c.H;
         if (c.fold) rc = layernorm768_split(c.XH, c.XL, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, s, c.m_dev, c.rows_hint);
         else rc = layernorm768(c.X, w->lnf_g, w->lnf_b, hf, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint);
         if (rc) return rc;
-        const bg_mlp_weights& m = w->fc_out;
         // (variable-length: the compact result rows are scattered into the zero-filled padded eps_out)
-        rc = embed_mlp(c, m, hf, 768, M, eps_out, m.n_out, nullptr, 0, 1, nullptr, 0, 1, false, true, false, false, false, true);
+        rc = embed_mlp(c, mo, hf, 768, M, eps_out, mo.n_out, nullptr, 0, 1, nullptr, 0, 1, false, true, false, false, false, true);
     }
     return rc;
 }

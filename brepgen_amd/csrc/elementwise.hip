@@ -143,6 +143,24 @@ int cond_vector(const float* temb, int nt, const float* cls, const int64_t* labe
     return launch_status("cond_vector");
 }
 
+__global__ void cond_vector_table_kernel(const float* __restrict__ table, int table_rows, const int64_t* __restrict__ ts, int nt,
+                                         const float* __restrict__ cls, const int64_t* __restrict__ label, float* __restrict__ c, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 768) return;
+    const int b = i / 768, col = i % 768;
+    const int64_t t = ts[nt == 1 ? 0 : b];
+    float v = (t >= 0 && t < table_rows) ? table[(size_t)t * 768 + col] : __builtin_nanf("");
+    if (cls != nullptr) v += cls[(size_t)label[b] * 768 + col];
+    c[i] = v;
+}
+
+int cond_vector_table(const float* table, int table_rows, const int64_t* timesteps, int nt, const float* cls, const int64_t* label,
+                      float* c, int B, hipStream_t s) {
+    const int total = B * 768;
+    hipLaunchKernelGGL(cond_vector_table_kernel, dim3((total + 255) / 256), dim3(256), 0, s, table, table_rows, timesteps, nt, cls, label, c, B);
+    return launch_status("cond_vector_table");
+}
+
 __global__ void cast_f32_bf16_kernel(const float4* __restrict__ in, bf16x4* __restrict__ out, size_t n4) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 v = in[i];

@@ -94,6 +94,10 @@ class _HipDenoiser(nn.Module):
         self.cache_conditioning = True   # reuse step-invariant conditioning embeds while the inputs are unchanged
         self.fuse_embed = True           # input embeds: Linear(k) + LayerNorm + SiLU as one kernel (k = 6 / 12 / 48)
         self.fold_layernorm = True       # 16-bit dtypes: norm1 / norm2 folded into the QKV / FFN1 GEMMs, split residual
+        self.fuse_output = True          # ... and net.norm folded into fc_out.0, LayerNorm + SiLU + Linear(768, c) as one launch
+        # the time-embedding MLP evaluated once for t = 0 .. time_table_steps - 1 (num_train_timesteps of the reference's schedulers,
+        # sample.py:101-117) and looked up per evaluation; 0 = recomputed per call.  A timestep outside the table gives NaN.
+        self.time_table_steps = 1000
         # Variable-length execution (nets that take a mask): only the VALID tokens run through the network (compacted on
         # the device, no host sync); eps at padded positions is 0 where the reference returns values nobody reads
         # (sample.py:284, 307-314).  False = dense execution, every position as the reference computes it.
@@ -124,10 +128,9 @@ class _HipDenoiser(nn.Module):
 
     def _pack(self, dt):
         fold = bool(self.fold_layernorm) and dt != torch.float32
-        fold = (fold, bool(self.fuse_embed))             # cache key of the packed descriptor
-        if (dt, fold) in self._packs:
-            return self._packs[(dt, fold)]
-        fold = fold[0]
+        key = (dt, fold, bool(self.fuse_embed), bool(self.fuse_output), int(self.time_table_steps or 0))   # of the packed descriptor
+        if key in self._packs:
+            return self._packs[key]
         keep = []                                        # owns every packed tensor the descriptor points to
         code = {torch.bfloat16: BG_BF16, torch.float16: BG_F16, torch.float32: BG_F32}[dt]
 
@@ -151,15 +154,25 @@ class _HipDenoiser(nn.Module):
 
         pad = 1 if dt == torch.float32 else 64
 
-        def mlp(seq, w0_compute=False):
+        def mlp(seq, w0_compute=False, fold_norm=None):
             m = _lib.MlpWeights()
             k_in, n_out = seq[0].in_features, seq[3].out_features
-            m.w0 = mat(seq[0].weight) if w0_compute else f32(seq[0].weight)
-            m.w0_dtype = code if w0_compute else BG_F32
-            m.w0_mfma = None
+            m.w0_mfma = m.w0_colsum = None
+            if fold_norm is not None:
+                # fc_out.0 behind the encoder's final LayerNorm (net.norm), folded like norm1 / norm2 into QKV / FFN1:
+                # LN(x) W0^T + b0 = rstd (x (gamma*W0)^T) - mean rstd colsum + (b0 + W0 beta)
+                w0 = seq[0].weight.detach().to(torch.float32)
+                m.w0 = mat(seq[0].weight, gamma=fold_norm.weight)
+                m.w0_colsum = f32(keep[-1].to(torch.float32).sum(1))
+                m.b0 = f32(seq[0].bias.detach().to(torch.float32) + (w0 * fold_norm.bias.detach().to(torch.float32)[None, :]).sum(1))
+                m.w0_dtype = code
+            else:
+                m.w0 = mat(seq[0].weight) if w0_compute else f32(seq[0].weight)
+                m.w0_dtype = code if w0_compute else BG_F32
+                m.b0 = f32(seq[0].bias)
             if not w0_compute and k_in in (6, 12, 48) and self.fuse_embed:
                 m.w0_mfma = f32(mfma_operand_order(seq[0].weight.detach().to(torch.float32)))
-            m.b0, m.ln_g, m.ln_b = f32(seq[0].bias), f32(seq[1].weight), f32(seq[1].bias)
+            m.ln_g, m.ln_b = f32(seq[1].weight), f32(seq[1].bias)
             m.w3 = mat(seq[3].weight, pad_to=pad)
             b3 = seq[3].bias.detach().to(torch.float32)
             if b3.numel() % pad:
@@ -198,12 +211,30 @@ class _HipDenoiser(nn.Module):
             L.w_2, L.b_2 = mat(layer.linear2.weight), f32(layer.linear2.bias)
         w.lnf_g, w.lnf_b = f32(self.net.norm.weight), f32(self.net.norm.bias)
         w.time_embed = mlp(self.time_embed)
-        w.fc_out = mlp(self.fc_out, w0_compute=True)
+        w.fc_out = mlp(self.fc_out, w0_compute=True, fold_norm=self.net.norm if (fold and self.fuse_output) else None)
         for i, name in enumerate(self.EMBEDS):
             w.embed[i] = mlp(getattr(self, name))
         w.class_embed = f32(self.class_embed.embed.weight) if self.use_cf else None
-        self._packs[(dt, (fold, bool(self.fuse_embed)))] = (w, keep)
-        return self._packs[(dt, (fold, bool(self.fuse_embed)))]
+        w.time_table, w.time_table_rows = None, 0
+        T = int(self.time_table_steps or 0)
+        dev = self.net.norm.weight.device
+        if T > 0 and dev.type == "cuda":
+            # sincos -> time_embed for every t the schedulers can ask for: a function of the weights only, evaluated ONCE by the
+            # library's own kernels; an evaluation then looks its timestep up (one launch instead of five small dependent ones)
+            lib = _lib.load()
+            ts = torch.arange(T, dtype=torch.int64, device=dev)
+            sc = torch.empty(T, D, dtype=torch.float32, device=dev)
+            table = torch.empty(T, D, dtype=torch.float32, device=dev)
+            scratch = torch.empty(lib.bg_embed_mlp_scratch_bytes(T, code), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                check(lib.bg_sincos_embed(ptr(ts), T, ptr(sc), stream()), "bg_sincos_embed")
+                check(lib.bg_embed_mlp_fwd(C.byref(w.time_embed), code, ptr(sc), D, T, ptr(table), D, None, 0, 1, ptr(scratch),
+                                           scratch.numel(), stream()), "bg_embed_mlp_fwd[time table]")
+            keep.append(table)
+            w.time_table, w.time_table_rows = ptr(table), T
+            # (sc / scratch / ts are only read by the launches above, which precede every later use of their storage on this stream)
+        self._packs[key] = (w, keep)
+        return self._packs[key]
 
     # ---- helpers ----------------------------------------------------------------------------------
     def _dtype(self):

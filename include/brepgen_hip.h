@@ -154,6 +154,11 @@ int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, cons
 int bg_qkv_attn_paired_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
                            void* out, void* qkv_dbg, const int* m_dev, const int* slot_desc, int slot_bound, int m_stats,
                            int dtype, float ln_eps, bg_stream_t stream);
+/* The tail of the denoisers' output MLP in one launch (csrc/out_tail.hip): out[m, :n_out] = W3 . SiLU(LayerNorm(t0[m, :])) + b3 with
+ * t0 [rows, 768] 16-bit rows of `dtype`, w3 [n_out_pad, 768] of the same dtype (the first 16 * ceil(n_out / 16) rows are read),
+ * b3 fp32 [n_out_pad], 1 <= n_out <= 48, out fp32 [rows, n_out]. */
+int bg_ln_silu_out_fwd(const void* t0, const float* ln_g, const float* ln_b, const void* w3, const float* b3, float* out,
+                       int n_out, int n_out_pad, int rows, int dtype, float eps, bg_stream_t stream);
 /* Slot-packed compaction for samples of at most 64 tokens (mask [B, n_mask], 1 = padded): every 64-row slot holds one or two whole
  * samples (shortest joins longest while the sum fits), the rows behind them are clones of the slot's first row.  offsets [B + 1]:
  * first row of every sample, offsets[B] = 64 * slots (stays on the device); src_row [64 B]; slot_desc [2 B]; slot_a [B]: the first
@@ -180,6 +185,10 @@ typedef struct {            /* Linear(k_in,768) -> LayerNorm -> SiLU -> Linear(7
     const float* w0_mfma;   /* optional, k_in in {6,12,48} with fp32 w0: W0 in MFMA operand order,
                                [24][k_in/2][64] with element (ct, kk, lane) = w0[ct*32 + (lane & 31)][2*kk + (lane >> 5)]:
                                selects the fused Linear + LayerNorm + SiLU kernel (bg_embed_ln_silu_fwd) */
+    const float* w0_colsum; /* fc_out only (16-bit modes with the LayerNorm fold; NULL elsewhere): the encoder's final LayerNorm
+                               (net.norm) is folded into fc_out.0 -- w0 = T(net.norm.weight * W0), b0 = b0 + W0 net.norm.bias,
+                               w0_colsum[n] = sum_k float(w0[n,k]) -- and the rest of the MLP (LayerNorm + SiLU + Linear(768, n_out))
+                               runs as one launch (bg_ln_silu_out_fwd) */
 } bg_mlp_weights;
 
 typedef struct {            /* one nn.TransformerEncoderLayer (norm_first) */
@@ -213,6 +222,12 @@ typedef struct {
      * EdgeZ: {surfp,surfz,edgep,edgez,vertp} */
     bg_mlp_weights embed[BG_MAX_EMBEDS];
     const float* class_embed;              /* fp32 [11,768] or NULL (use_cf=False) */
+    /* optional: the time-embedding MLP (sincos -> time_embed) evaluated once for t = 0 .. time_table_rows - 1, fp32
+     * [time_table_rows, 768] -- a function of the weights only; with it an evaluation looks its timestep(s) up instead of running
+     * the five small launches of that MLP (a timestep outside the table yields NaN).  NULL: computed per call. */
+    const float* time_table;
+    int time_table_rows;
+    int _pad3;
 } bg_denoiser_weights;
 
 typedef struct {

@@ -186,3 +186,15 @@ def attention(qkv, key_pad, B, N):
     out = torch.empty(B * N, 768, device=qkv.device, dtype=qkv.dtype)
     check(_lib.load().bg_attn_fwd(ptr(qkv), ptr(kp), ptr(out), B, N, bg_dtype(qkv.dtype), stream()), "bg_attn_fwd")
     return out
+
+
+def ln_silu_out(t0, gamma, beta, w3, b3, n_out, eps=1e-5):
+    """bg_ln_silu_out_fwd: W3 . SiLU(LayerNorm(t0)) + b3 in one launch; t0 [rows, 768] 16-bit, w3 [n_out_pad, 768] same dtype."""
+    _need_cuda(t0, gamma, beta, w3, b3)
+    assert t0.dim() == 2 and t0.shape[1] == 768 and w3.dtype == t0.dtype and w3.shape[1] == 768
+    t0, w3 = t0.contiguous(), w3.contiguous()
+    out = torch.empty(t0.shape[0], n_out, device=t0.device, dtype=torch.float32)
+    check(_lib.load().bg_ln_silu_out_fwd(ptr(t0), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(w3), ptr(b3.contiguous()),
+                                         ptr(out), n_out, w3.shape[0], t0.shape[0], bg_dtype(t0.dtype), eps, stream()),
+          "bg_ln_silu_out_fwd")
+    return out

@@ -1,0 +1,103 @@
+"""-m gpu: round-5 additions -- the fused tail of the output MLP (csrc/out_tail.hip) against plain torch fp32 math, the final
+LayerNorm folded into fc_out.0, the precomputed time-embedding table, and oracle-backed checks that drive the round-4 kernels
+(fused QKV + attention, pipelined split-residual GEMM) DIRECTLY on exactly representable operands, so that their oracle leg is
+tighter than 16-bit noise.  Measured numbers -> gpurun_out/parity_r05.json."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+F32, F16, BF16 = torch.float32, torch.float16, torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import parity_cases
+    return parity_cases
+
+
+def _record(key, value):
+    path = os.path.join(ROOT, "gpurun_out", "parity_r05.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    d[key] = value
+    with open(path, "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
+# ---- out_tail.hip: W3 . SiLU(LayerNorm(t0)) + b3 ---------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("n_out", [6, 18, 48])
+@pytest.mark.parametrize("rows", [1, 17, 1000, 4099])
+def test_ln_silu_out_vs_torch_fp32(pc, dt, n_out, rows):
+    import hip_ops as ops
+    g = torch.Generator().manual_seed(rows * 100 + n_out)
+    t0 = (torch.randn(rows, 768, generator=g) * 1.7 + 0.3).to(dt)
+    gamma, beta = 1 + 0.2 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    w3 = (torch.randn(64, 768, generator=g) * 0.05).to(dt)
+    b3 = torch.randn(64, generator=g)
+    got = ops.ln_silu_out(t0.cuda(), gamma.cuda(), beta.cuda(), w3.cuda(), b3.cuda(), n_out).cpu()
+    # the kernel's arithmetic in plain torch: fp32 LayerNorm of the 16-bit rows, SiLU, rounded to the operand dtype, fp32 product
+    x = t0.double()
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    h = (x - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    h = (h * torch.sigmoid(h)).float().to(dt)
+    want = (h.double() @ w3[:n_out].double().T + b3[:n_out].double()).float()
+    err = float((got - want).abs().max())
+    # (a SiLU value within an ulp of a 16-bit rounding boundary may round the other way: one flip moves an output by 2^-9 * |h w|)
+    assert torch.isfinite(got).all() and err < (4e-3 if dt == BF16 else 6e-4) * max(1.0, float(want.abs().max())), err
+
+
+@pytest.mark.parametrize("net", ["SurfPosNet", "SurfZNet", "EdgeZNet"])
+def test_fused_output_path_vs_unfused_and_oracle(pc, net):
+    """net.fuse_output (final LayerNorm folded into fc_out.0 + the one-launch tail) against the four-launch path it replaces and
+    against the fp32 oracle: both 16-bit paths sit at the same distance from the truth."""
+    S, E = (8, 12) if net == "EdgeZNet" else (60, 1)
+    m, sd = pc.build_net(net, 11, False, BF16)
+    args = pc.synth_inputs(net, 3, S, E, False)
+    cu = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    with torch.no_grad():
+        want = pc.orc.FORWARD[net](sd, *args)
+        fused = m(*cu).cpu()
+        m.fuse_output = False
+        plain = m(*cu).cpu()
+    mask = args[3] if net == "SurfZNet" else (args[5] if net == "EdgeZNet" else None)
+    valid = ~mask if mask is not None else torch.ones(want.shape[:-1], dtype=torch.bool)
+    ef, ep = float((fused - want)[valid].abs().max()), float((plain - want)[valid].abs().max())
+    mf, mp = float((fused - want)[valid].abs().mean()), float((plain - want)[valid].abs().mean())
+    _record("fused_output_vs_unfused_" + net, {"fused_max": ef, "unfused_max": ep, "fused_mean": mf, "unfused_mean": mp})
+    assert not torch.equal(fused, plain)
+    assert ef < 3e-2 and ep < 3e-2 and mf < 1.25 * mp + 1e-4, (ef, ep, mf, mp)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_time_table_equals_per_call_time_mlp(pc, dt):
+    """The precomputed time-embedding table against the per-call MLP (time_table_steps = 0): same eps up to the last bits of two
+    GEMM orders (M = 1 GEMV vs M = 1000 MFMA rows); per-sample timesteps look the same rows up as a shared one."""
+    m, sd = pc.build_net("SurfPosNet", 5, False, dt)
+    x = torch.randn(4, 30, 6, generator=torch.Generator().manual_seed(3)).cuda()
+    t1 = torch.tensor([437]).cuda()
+    with torch.no_grad():
+        a = m(x, t1, None)
+        b = m(x, t1.repeat(4), None)
+        m.time_table_steps = 0
+        c = m(x, t1, None)
+    assert torch.equal(a, b)
+    d = float((a - c).abs().max())
+    assert d < (2e-6 if dt == F32 else 2e-2), d
+    # a timestep outside the table fails loudly (NaN), it is never clamped
+    m.time_table_steps = 1000
+    with torch.no_grad():
+        bad = m(x, torch.tensor([1000]).cuda(), None)
+    assert torch.isnan(bad).all()
