@@ -22,6 +22,12 @@ namespace bg {
 
 typedef __attribute__((ext_vector_type(4))) unsigned ot_u32x4;
 
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the value is rounded to 16 bits next): the IEEE division of silu_f is ten
+// VALU instructions per element, and this kernel issues 768 of them per token
+__device__ __forceinline__ float silu_rcp(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+
 template <bool F16, int NT>
 __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict__ t0, const float* __restrict__ gam,
                                                           const float* __restrict__ bet, const void* __restrict__ w3,
@@ -37,12 +43,27 @@ __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict
     const int r16 = lane & 15, g = lane >> 4;
     const int Mv = m_dev ? *m_dev : M;
 
+    // the wave's first 16 tokens are requested BEFORE the LDS images are filled (24 x 16-byte loads per lane in flight): at the
+    // face-LDM sizes a wave owns one or two blocks, so this is most of the overlap there is
+    const int n_blk = (Mv + 15) >> 4;
+    int blk = blockIdx.x * 8 + wave;
+    ot_u32x4 v[24];
+    auto request = [&](int b) {
+        int row = (b << 4) + r16;
+        row = row < Mv ? row : Mv - 1;
+        row = row < 0 ? 0 : row;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(t0) + ((size_t)row * D + g * 8) * 2;
+#pragma unroll
+        for (int s = 0; s < 24; ++s) v[s] = *reinterpret_cast<const ot_u32x4*>(src + s * 64);
+    };
+    if (blk < n_blk) request(blk);
+
     // ---- W3 rows (the first 16 NT of the padded matrix) -> LDS, chunk' = chunk ^ (row & 15) inside its aligned group of 16 chunks;
     // gamma, beta beside them ----
     for (int c = threadIdx.x; c < NT * 16 * (D / 8); c += 512) {
         const int row = c / (D / 8), ch = c % (D / 8);
-        const ot_u32x4 v = *reinterpret_cast<const ot_u32x4*>(reinterpret_cast<const unsigned char*>(w3) + ((size_t)row * D + ch * 8) * 2);
-        *reinterpret_cast<ot_u32x4*>(w_img + row * (D * 2) + ((ch ^ (row & 15)) << 4)) = v;
+        const ot_u32x4 w = *reinterpret_cast<const ot_u32x4*>(reinterpret_cast<const unsigned char*>(w3) + ((size_t)row * D + ch * 8) * 2);
+        *reinterpret_cast<ot_u32x4*>(w_img + row * (D * 2) + ((ch ^ (row & 15)) << 4)) = w;
     }
     for (int c = threadIdx.x; c < D; c += 512) { gb[0][c] = gam[c]; gb[1][c] = bet[c]; }
     __syncthreads();
@@ -51,15 +72,8 @@ __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t) bias[t] = (t * 16 + r16) < n_out ? b3[t * 16 + r16] : 0.f;
 
-    const int n_blk = (Mv + 15) >> 4;
-    for (int blk = blockIdx.x * 8 + wave; blk < n_blk; blk += gridDim.x * 8) {
+    for (; blk < n_blk; blk += gridDim.x * 8) {
         const int r0 = blk << 4;
-        int row = r0 + r16;
-        row = row < Mv ? row : Mv - 1;
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(t0) + ((size_t)row * D + g * 8) * 2;
-        ot_u32x4 v[24];
-#pragma unroll
-        for (int s = 0; s < 24; ++s) v[s] = *reinterpret_cast<const ot_u32x4*>(src + s * 64);
 
         // ---- row statistics, two passes over the registers; a row lives in the four lanes r16, r16 + 16, + 32, + 48 ----
         float sum = 0.f;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict
                 for (int e = 0; e < 4; ++e) { f[e] = a4[e]; f[4 + e] = b4[e]; }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = silu_f((f[e] - mean) * rstd * gg[e] + bb[e]);
+            for (int e = 0; e < 8; ++e) f[e] = silu_rcp((f[e] - mean) * rstd * gg[e] + bb[e]);
             union { V8 v8; uint2 u[2]; } a;
             a.u[0] = pack4_16(f[0], f[1], f[2], f[3], F16 ? BG_F16 : BG_BF16);
             a.u[1] = pack4_16(f[4], f[5], f[6], f[7], F16 ? BG_F16 : BG_BF16);
@@ -140,6 +154,7 @@ __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict
                 if (col < n_out) out[orow * n_out + col] = acc[t][r] + bias[t];
             }
         }
+        if (blk + (int)gridDim.x * 8 < n_blk) request(blk + gridDim.x * 8);
     }
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """In-process A/B of bg_tune settings on the three face-LDM loops of bench.py (one box, one process, interleaved rounds):
-    python tools/face_ldm_ab.py "10=2" "10=0" ...        each argument = one setting (key=value,...); BG_SPLITS=1,2,4: the n_split values"""
+    python tools/face_ldm_ab.py "10=2" "10=0" ...        each argument = one setting (key=value,...); BG_SPLITS=1,2,4: the n_split values
+A key that is not a number names an attribute of the two drop-in modules instead (e.g. "fuse_output=0,time_table_steps=0")."""
 import os
 import statistics
 import sys
@@ -14,19 +15,28 @@ import bench
 from brepgen_amd import _lib
 
 SETTINGS = sys.argv[1:] or ["10=2", "10=0"]
-KEYS = sorted({int(kv.split("=")[0]) for s in SETTINGS for kv in s.split(",") if kv})
+KEYS = sorted({int(kv.split("=")[0]) for s in SETTINGS for kv in s.split(",") if kv and kv.split("=")[0].isdigit()})
+ATTRS = sorted({kv.split("=")[0] for s in SETTINGS for kv in s.split(",") if kv and not kv.split("=")[0].isdigit()})
 lib = _lib.load()
 dev = torch.device("cuda")
 ldm = bench.FaceLDM(dev, 0)
 STEPS, ROUNDS = 20, 3
+DEFAULTS = {a: getattr(ldm.pos_net, a) for a in ATTRS}
 
 
 def apply(setting):
     for k in KEYS:
         lib.bg_tune_set(k, 0)
+    for a, d in DEFAULTS.items():
+        for net in (ldm.pos_net, ldm.z_net):
+            setattr(net, a, d)
     for kv in filter(None, setting.split(",")):
         k, v = kv.split("=")
-        lib.bg_tune_set(int(k), int(v))
+        if k.isdigit():
+            lib.bg_tune_set(int(k), int(v))
+        else:
+            for net in (ldm.pos_net, ldm.z_net):
+                setattr(net, k, type(DEFAULTS[k])(int(v)))
 
 
 def clock(ks):
