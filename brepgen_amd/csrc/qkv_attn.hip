@@ -80,6 +80,7 @@ struct QkvAttnArgs {
     // exist (a multiple of 64), slot_desc[2 k] / [2 k + 1] = the lengths of slot k's samples; B is then the slot bound, N = 64
     const int* m_dev = nullptr;
     const int* slot_desc = nullptr;
+    int pin = 0;              // 1: XCD-pinned tile walk (see the kernel)
 };
 
 __device__ __forceinline__ int qa_opaque(int x) {
@@ -110,7 +111,24 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     const int T_all = n_groups * BG_N_HEAD;
     const int G = gridDim.x;
     int L = xcd_remap(blockIdx.x, G);
-    if (L >= T_all) return;
+    // XCD-pinned walk (large launches): XCD x = blockIdx.x & 7 keeps ONE half of the heads for the whole launch (x & 1) and a quarter
+    // of the sample groups (x >> 1), so its L2 holds 6 heads' weights (1.8 MB) while the A panels stream through -- with the plain
+    // walk every XCD runs all 12 heads, the 3.5 MB of W' plus the round's A panels overflow the 4 MiB L2 and W' is re-fetched from
+    // the fabric in every round of tiles (PMC: 181 -> 139 MB of reads per launch at 512 x 60, launch -3...-9 %, step -1...-2 %:
+    // profiles/r05/qkv_attn_tile_walk_*.log).  L then counts the XCD's own tiles: tile j -> group 4 (j / 6) + (x >> 1), head
+    // 6 (x & 1) + j % 6, j advancing by the XCD's workgroup count.
+    const bool pin = g.pin != 0;
+    const int pin_q = (blockIdx.x & 7) >> 1, pin_h0 = (blockIdx.x & 1) * 6, pin_step = G >> 3;
+    auto tile_of = [&](int l, int& tg, int& th) -> bool {
+        if (pin) { tg = 4 * (l / 6) + pin_q; th = pin_h0 + l % 6; return tg < n_groups; }
+        tg = l / BG_N_HEAD; th = l % BG_N_HEAD;
+        return l < T_all;
+    };
+    if (pin) L = blockIdx.x >> 3;
+    {
+        int tg, th;
+        if (!tile_of(L, tg, th)) return;
+    }
 
     const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.a);
     const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.w);
@@ -124,6 +142,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
     };
+
     auto bar = [&]() {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -235,7 +254,8 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     const unsigned char* b0 = lds;
     const unsigned char* b1 = lds + QA_BUF;
 
-    int grp = L / BG_N_HEAD, head = L % BG_N_HEAD;
+    int grp, head;
+    tile_of(L, grp, head);
     // LayerNorm-fold coefficients (rstd, -mean rstd) of the lane's token of row tile i, from the staged partials -- in two light steps
     // (sums of the twelve partials; the coefficients) that fit behind an 8-MFMA segment of the partner wave
     float2 cf[2];
@@ -274,9 +294,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         // here: buffer 0 = K-step 0 of this tile, landed and visible; A rows of K-step 1 in flight; every wave at the same barrier
         if (late) bar();
         const unsigned char* w_cur = Wb + (size_t)head * 64 * ldw_b;
-        const int Ln = L + G;
-        const bool has_next = Ln < T_all;
-        const int grp_n = Ln / BG_N_HEAD, head_n = Ln % BG_N_HEAD;
+        const int Ln = L + (pin ? pin_step : G);
+        int grp_n, head_n;
+        const bool has_next = tile_of(Ln, grp_n, head_n);
         const unsigned char* w_nxt = Wb + (size_t)head_n * 64 * ldw_b;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -548,6 +568,15 @@ bool qkv_attn_worthwhile(int B, int N) {
     return tiles <= 256 || tiles >= 352;
 }
 
+// the XCD-pinned walk needs whole octets of workgroups (block b runs on XCD b % 8) and pays from two rounds of tiles on: below that the
+// XCDs' shares (a quarter of the sample groups x 6 heads each) are too uneven (37 samples x 60 tokens: 20.7 -> 34.6 us).  bg_tune key
+// 14: 1 = never, 2 = wherever the grid allows (the bit-equality tests).
+static int qkv_attn_pinned_walk(int tiles, int grid) {
+    const int t = g_tune[TUNE_QKV_WALK];
+    if (t == 1 || (grid & 7) != 0) return 0;
+    return (t == 2 || tiles >= 512) ? 1 : 0;
+}
+
 int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
     const int S = g.N <= 32 ? 32 : 64, spt = 256 / S;
     const int tiles = (g.B + spt - 1) / spt * BG_N_HEAD;
@@ -557,7 +586,9 @@ int qkv_attention_launch(const QkvAttnArgs& g, int dtype, hipStream_t s) {
                    rows * (2.0 * BG_D_MODEL * 2 + FOLD_PARTS * 8.0) + 2.0 * 3 * BG_D_MODEL * BG_D_MODEL + 2 * 4.0 * 3 * BG_D_MODEL, s);
     const int grid = tiles < 256 ? tiles : 256;
     const bool f16 = dtype == BG_F16;
-#define QA_LAUNCH(F, SS, MK, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, MK, D>), dim3(grid), dim3(512), 0, s, g)
+    QkvAttnArgs ge = g;
+    ge.pin = qkv_attn_pinned_walk(tiles, grid);
+#define QA_LAUNCH(F, SS, MK, D) hipLaunchKernelGGL((qkv_attn_kernel<F, SS, MK, D>), dim3(grid), dim3(512), 0, s, ge)
 #define QA_PICK(MK, D)                                                                                     \
     do {                                                                                                   \
         if (S == 64) { if (f16) QA_LAUNCH(true, 64, MK, D); else QA_LAUNCH(false, 64, MK, D); }           \
@@ -583,6 +614,7 @@ int qkv_attention_paired(const void* x_hi, const void* w_qkv, const float* bias,
     g.m_dev = m_dev;
     g.slot_desc = slot_desc;
     const int tiles = (slot_bound + 3) / 4 * BG_N_HEAD;           // upper bound: the kernel reads the row count on the device
+    g.pin = qkv_attn_pinned_walk(tiles, tiles < 256 ? tiles : 256);
     // (opt-in profiler only: executed rows and attention pairs = sum over the samples of n^2, from the caller's host-side estimates;
     //  without them the slot bound -- every slot full, one sample of 64 tokens each)
     const double rows = rows_hint > 0 ? rows_hint : 64.0 * slot_bound;

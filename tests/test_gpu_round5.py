@@ -101,3 +101,53 @@ def test_time_table_equals_per_call_time_mlp(pc, dt):
     with torch.no_grad():
         bad = m(x, torch.tensor([1000]).cuda(), None)
     assert torch.isnan(bad).all()
+
+
+# ---- qkv_attn.hip: the XCD-pinned tile walk -----------------------------------------------------------------------------------
+@pytest.fixture
+def tune():
+    from brepgen_amd import _lib
+    lib = _lib.load()
+    yield lib.bg_tune_set
+    for k in (12, 13, 14):
+        lib.bg_tune_set(k, 0)
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,N", [(512, 60), (300, 48), (37, 60), (130, 30), (8, 60), (67, 64)])
+def test_qkv_attn_pinned_walk_is_bit_identical(pc, tune, dt, B, N):
+    """bg_tune key 14: 1 = plain walk, 2 = XCD-pinned head halves wherever the grid allows (a different ORDER of the same tiles)."""
+    import hip_ops as ops
+    g = torch.Generator().manual_seed(B * 7 + N)
+    M = B * N
+    x = torch.randn(M, 768, generator=g) * 2
+    grp = x.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().cuda()
+    w = (torch.randn(2304, 768, generator=g) * 0.04).to(dt).cuda()
+    b = torch.randn(2304, generator=g).cuda()
+    cs = w.float().sum(1).contiguous()
+    a = x.to(dt).cuda()
+    outs = []
+    for walk in (1, 2, 0):
+        tune(14, walk)
+        outs.append(ops.qkv_attention(a, w, b, cs, stats, B, N))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("ns", [1, 2])
+def test_pinned_walk_inside_the_denoisers(pc, tune, ns):
+    """SurfPosNet (equal lengths) and SurfZNet (ragged, slot-packed PAIR variant, device-side tile count) at a size that takes the
+    pinned walk by default: eps bit-identical to the plain walk."""
+    for net, B in (("SurfPosNet", 256), ("SurfZNet", 300)):
+        m, _ = pc.build_net(net, 4, False, BF16, varlen=True)
+        m.n_split = ns
+        args = pc.synth_inputs(net, B, 60, 1, False)
+        cu = [a.cuda() if torch.is_tensor(a) else a for a in args]
+        res = []
+        with torch.no_grad():
+            for walk in (1, 2, 0):
+                tune(14, walk)
+                res.append(m(*cu))
+        torch.cuda.synchronize()
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), net
