@@ -151,3 +151,103 @@ def test_pinned_walk_inside_the_denoisers(pc, tune, ns):
                 res.append(m(*cu))
         torch.cuda.synchronize()
         assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), net
+
+
+# ---- oracle legs tighter than 16-bit noise for the round-4 kernels ---------------------------------------------
+# The round-4 tests prove these kernels EQUAL to the launches they replace; the chain to the oracle ran only through whole-network
+# goldens at 16-bit tolerance.  Here each is driven directly and checked against fp64 torch math of its own definition: one 16-bit
+# rounding of the q|k|v image, fp32-accumulation noise on the residual stream, an exactly representable softmax.
+def _fold_case(M, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(M, 768, generator=g) * 2).to(dt)             # the raw residual rows the GEMM reads (hi plane)
+    xf = x.double()
+    grp = xf.reshape(M, 12, 64)
+    stats = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2).contiguous().float()
+    w = torch.randn(2304, 768, generator=g) * 0.04
+    w[:768] *= 0.125
+    w = w.to(dt)
+    b = torch.randn(2304, generator=g)
+    return x, stats, w, b
+
+
+def _qkv_fp64(x, w, b):
+    """q|k|v of the LayerNorm-fold GEMM in fp64: rstd (x W'^T) - mean rstd colsum + b' (bg_common.h: ln_fold_coeffs / ln_fold_apply)."""
+    xf, wf = x.double(), w.double()
+    mean = xf.mean(-1, keepdim=True)
+    var = (xf * xf).mean(-1, keepdim=True) - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp_min(0) + 1e-5)
+    return rstd * (xf @ wf.T) - mean * rstd * wf.sum(1)[None, :] + b.double()[None, :]
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("B,N", [(64, 60), (300, 30), (9, 64)])
+def test_fused_qkv_image_is_one_rounding_from_fp64(pc, dt, B, N):
+    """The q|k|v image of bg_qkv_attn_fwd against the fp64 value of its definition: within ONE rounding of the operand dtype (half an
+    ulp = 2^-8 / 2^-11 relative, plus the fp32 accumulation noise of a 768-term product) -- not the 1e-2 of a whole network."""
+    import hip_ops as ops
+    x, stats, w, b = _fold_case(B * N, dt, B + N)
+    cs = w.float().sum(1)
+    out, img = ops.qkv_attention(x.cuda(), w.cuda(), b.cuda(), cs.cuda(), stats.cuda(), B, N, want_qkv=True)
+    want = _qkv_fp64(x, w, b)
+    err = (img.cpu().double() - want).abs()
+    half_ulp = 2.0 ** (-8 if dt == BF16 else -11)                # relative half-spacing of 8 / 11 significant bits
+    bound = half_ulp * want.abs() * 1.001 + 3e-5                  # (fp16 subnormals: values below 6e-5 carry an absolute step)
+    assert bool((err <= bound).all()), float((err - bound).max())
+    # and the attention, from the kernel's OWN q|k|v image in fp64 (q carries the 1/8): only P's and the output's roundings remain
+    q, k, v = (img.cpu().double().reshape(B, N, 3, 12, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2), -1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * N, 768)
+    ea = float((out.cpu().double() - ref).abs().max())
+    _record(f"fused_qkv_attention_vs_fp64_{str(dt)[6:]}_B{B}_N{N}", {"image_max_err_over_bound": float((err / bound).max()), "attn_max_abs": ea})
+    assert ea < (2e-2 if dt == BF16 else 3e-3) * max(1.0, float(ref.abs().max())), ea
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("N", [32, 64])
+def test_fused_attention_with_exact_softmax(pc, dt, N):
+    """q = 0 (zero W'_q rows and bias): every score is 0, p = 1 / N exactly (N a power of two), the output is the mean of v over the
+    sample's keys -- P carries no rounding, so the launch must match fp64 to the output's own rounding."""
+    import hip_ops as ops
+    B = 40
+    x, stats, w, b = _fold_case(B * N, dt, 5 * N)
+    w[:768] = 0
+    b[:768] = 0
+    cs = w.float().sum(1)
+    out, img = ops.qkv_attention(x.cuda(), w.cuda(), b.cuda(), cs.cuda(), stats.cuda(), B, N, want_qkv=True)
+    v = img.cpu().double().reshape(B, N, 3, 768)[:, :, 2]
+    ref = v.mean(1, keepdim=True).expand(B, N, 768).reshape(B * N, 768)
+    err = (out.cpu().double() - ref).abs()
+    half_ulp = 2.0 ** (-8 if dt == BF16 else -11)                # relative half-spacing of 8 / 11 significant bits
+    assert float(img[:, :768].float().abs().max()) == 0.0
+    assert bool((err <= half_ulp * ref.abs() * 1.01 + 2e-5).all()), float(err.max())
+
+
+@pytest.mark.parametrize("dt", [BF16, F16])
+@pytest.mark.parametrize("K", [768, 1024])
+def test_split_pipe_gemm_vs_fp64(pc, dt, K):
+    """The pipelined split-residual GEMM (out-proj / FFN2 form; 10 000 rows -> the gemm_split.hip kernel, ragged last panel) against
+    fp64: hi + lo reproduces v = a W^T + b + (res_hi + res_lo) to fp32-accumulation noise plus the lo plane's rounding (2^-16 / 2^-22
+    relative), hi is the correctly rounded v wherever v is not within that noise of a rounding boundary, and the row statistics are
+    the sums of v."""
+    import hip_ops as ops
+    M = 10000
+    g = torch.Generator().manual_seed(K)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    xr = rn(M, 768) * 2
+    hi = xr.to(dt)
+    lo = (xr - hi.float()).to(dt)
+    a, w, b = (rn(M, K) * 0.5).to(dt), (rn(768, K) * 0.04).to(dt), rn(768)
+    r = ops.linear_ex(a.cuda(), w.cuda(), b.cuda(), split_out=True, res=(hi.cuda(), lo.cuda()), want_stats=True)
+    v = a.double() @ w.double().T + b.double() + hi.double() + lo.double()
+    got = r["out"].cpu().double() + r["lo"].cpu().double()
+    lo_ulp = 2.0 ** (-16 if dt == BF16 else -22)                  # half-spacing of the lo plane relative to v
+    err = (got - v).abs()
+    assert bool((err <= lo_ulp * v.abs() + 2e-5).all()), float(err.max())
+    hi_want = v.float().to(dt)
+    frac = float((r["out"].cpu() != hi_want).float().mean())
+    assert frac < 2e-3, frac                                      # (only values within fp32 noise of a rounding boundary)
+    grp = v.reshape(M, 12, 64)
+    st = torch.stack([grp.sum(-1), (grp * grp).sum(-1)], -1).permute(1, 0, 2)
+    es = float(((r["stats"].cpu().double() - st).abs() / (1 + st.abs())).max())
+    _record(f"split_pipe_vs_fp64_{str(dt)[6:]}_K{K}", {"hi_plus_lo_max_err": float(err.max()), "hi_mismatch_fraction": frac, "stats_rel": es})
+    assert es < 2e-5, es
