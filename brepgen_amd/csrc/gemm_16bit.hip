@@ -902,6 +902,10 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     gemm_cost(g, rows_tail, fl_t, by_t);
     // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes the rows the 256 x 256
     // kernel does not (bg_tune key 12 = 1: the 128 x 128 persistent kernel's split epilogue instead, for the bit-equality tests)
+    if ((g_tune[TUNE_SPLIT_PIPE] == 3 || g_tune[TUNE_SPLIT_PIPE] == 4) && split3_eligible(g_)) {    // (round 5: 256 x 128 tile, three-slot ring)
+        ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
+        return launch_split3<F16>(g_, s);
+    }
     if (g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g_)) {
         ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
         return launch_split_pipe<F16>(g_, s);
