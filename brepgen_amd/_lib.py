@@ -44,7 +44,7 @@ class DenoiserInputs(C.Structure):
                 ("x", fp), ("surf_pos", fp), ("surf_z", fp), ("edge_pos", fp), ("mask", u8p),
                 ("timesteps", i64p), ("class_label", i64p), ("cond_cache", fp),
                 ("cond_cache_valid", C.c_int), ("varlen", C.c_int), ("rows_hint", C.c_double),
-                ("pairs_hint", C.c_double), ("n_split", C.c_int), ("_pad2", C.c_int)]
+                ("pairs_hint", C.c_double), ("n_split", C.c_int), ("_pad2", C.c_int), ("rows_plan", C.c_double * 4)]
 
 
 class GemmDesc(C.Structure):          # bg_gemm_desc

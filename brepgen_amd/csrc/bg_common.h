@@ -120,6 +120,7 @@ struct GemmArgs {
     const int* row_map = nullptr;
     int map_add = 0, map_add2 = 0, map_out = 0;
     double rows_hint = 0.0;           // host-side estimate of *m_dev (0 = unknown): kernel choice in launch16 + profiler accounting
+    double rows_plan = 0.0;           // *m_dev as the caller knows it EXACTLY (0 = not known): kernel choice only (brepgen_hip.h: rows_plan)
     // ---- implicit-GEMM convolution (16-bit operands, persistent kernel only; csrc/gemm_16bit.hip) ----
     // cv_C > 0: `a` is a channels-last activation tensor [S, H, W, C] (already normalised / activated), row m of the GEMM is
     // output pixel (s, oy, ox) of the 'same' stride-1 convolution on the nearest-upsampled grid (H << up, W << up), and

@@ -124,6 +124,7 @@ struct Ctx {
     const int* slot_desc = nullptr;   // slot-packed batch: (n_a, n_b) per 64-row slot (compact_rows_paired)
     int N_tok = 1;                    // tokens per sample of the padded layout
     double rows_hint = 0.0, pairs_hint = 0.0;   // host-side estimates: GEMM kernel choice + profiler accounting (brepgen_hip.h)
+    double rows_plan = 0.0;                     // the row count the caller knows exactly (0 = not): launch plan only
     int concurrent = 0;               // sibling sample groups are in flight on forked streams (n_split > 1)
 };
 
@@ -234,6 +235,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         c.offsets = offs; c.m_dev = offs + B; c.src_row = srow; c.rule = offs + B + 2;
         c.rows_hint = in->rows_hint > 0 ? in->rows_hint : 0.0;
         c.pairs_hint = in->pairs_hint > 0 ? in->pairs_hint : 0.0;
+        c.rows_plan = in->rows_plan[0] > 0 ? in->rows_plan[0] : 0.0;
         // padded positions of the result are defined as 0 (the valid rows are scattered over this)
         const hipError_t he = hipMemsetAsync(eps_out, 0, (size_t)Mpad * w->fc_out.n_out * sizeof(float), s);
         BG_REQUIRE(he == hipSuccess, (int)he, "bg_denoiser_fwd: hipMemsetAsync failed: %s", hipGetErrorString(he));
@@ -317,7 +319,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         const bg_layer_weights& L = w->layers[li];
         GemmArgs qkv{c.XH, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         qkv.stats_in = c.stats; qkv.colsum = L.qkv_colsum;
-        qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.concurrent = c.concurrent;
+        qkv.m_dev = c.m_dev; qkv.rule_table = c.rule; qkv.rows_hint = c.rows_hint; qkv.rows_plan = c.rows_plan; qkv.concurrent = c.concurrent;
         if (paired) {
             // ragged batch, slot-packed: one or two whole samples per 64-row slot (qkv_attn.hip, PAIR)
             if ((rc = qkv_attention_paired(c.XH, L.w_qkv, L.b_qkv, L.qkv_colsum, c.stats, c.H, nullptr, c.m_dev, c.slot_desc,
@@ -332,20 +334,20 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         }
         GemmArgs op{c.H, 768, L.w_o, L.b_o, c.XH, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
-        op.m_dev = c.m_dev; op.rule_table = c.rule; op.rows_hint = c.rows_hint; op.concurrent = c.concurrent;
+        op.m_dev = c.m_dev; op.rule_table = c.rule; op.rows_hint = c.rows_hint; op.rows_plan = c.rows_plan; op.concurrent = c.concurrent;
         if ((rc = gemm(op, c.dtype, s))) return rc;
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
-        f1.m_dev = c.m_dev; f1.rule_table = c.rule; f1.rows_hint = c.rows_hint; f1.concurrent = c.concurrent;
+        f1.m_dev = c.m_dev; f1.rule_table = c.rule; f1.rows_hint = c.rows_hint; f1.rows_plan = c.rows_plan; f1.concurrent = c.concurrent;
         if ((rc = gemm(f1, c.dtype, s))) return rc;
         GemmArgs f2{c.R, 1024, L.w_2, L.b_2, c.XH, 768, M, 768, 768, 1024, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         f2.out_lo = c.XL; f2.res_hi = c.XH; f2.res_lo = c.XL; f2.ld_res = 768; f2.stats_out = c.stats;
-        f2.m_dev = c.m_dev; f2.rule_table = c.rule; f2.rows_hint = c.rows_hint; f2.concurrent = c.concurrent;
+        f2.m_dev = c.m_dev; f2.rule_table = c.rule; f2.rows_hint = c.rows_hint; f2.rows_plan = c.rows_plan; f2.concurrent = c.concurrent;
         if ((rc = gemm(f2, c.dtype, s))) return rc;
     }
     for (int li = 0; !c.fold && li < w->n_layer; ++li) {
         const bg_layer_weights& L = w->layers[li];
-        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rule_table = c.rule; g.rows_hint = c.rows_hint; g.concurrent = c.concurrent; };
+        auto vl = [&](GemmArgs& g) { g.m_dev = c.m_dev; g.rule_table = c.rule; g.rows_hint = c.rows_hint; g.rows_plan = c.rows_plan; g.concurrent = c.concurrent; };
         if ((rc = layernorm768(c.X, L.ln1_g, L.ln1_b, c.H, c.dtype, M, 1e-5f, 0, s, c.m_dev, c.rows_hint))) return rc;
         GemmArgs qkv{c.H, 768, L.w_qkv, L.b_qkv, c.R, 2304, M, 2304, 2304, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         vl(qkv);
@@ -373,7 +375,7 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         // [M, 768] intermediate crosses HBM once, in 16 bits
         GemmArgs g0{c.XH, 768, mo.w0, mo.b0, c.H, 768, M, 768, 768, 768, c.dtype, BG_ACT_NONE, nullptr, 0, 1};
         g0.stats_in = c.stats; g0.colsum = mo.w0_colsum;
-        g0.m_dev = c.m_dev; g0.rule_table = c.rule; g0.rows_hint = c.rows_hint; g0.concurrent = c.concurrent;
+        g0.m_dev = c.m_dev; g0.rule_table = c.rule; g0.rows_hint = c.rows_hint; g0.rows_plan = c.rows_plan; g0.concurrent = c.concurrent;
         if ((rc = gemm(g0, c.dtype, s))) return rc;
         // (variable-length: the compact result rows are scattered into the zero-filled padded eps_out)
         return ln_silu_out(c.H, mo.ln_g, mo.ln_b, mo.w3, mo.b3, eps_out, mo.n_out, mo.n_out_pad, M, c.dtype, 1e-5f, s, c.m_dev,
@@ -545,6 +547,7 @@ extern "C" int bg_denoiser_fwd(const bg_denoiser_weights* w, const bg_denoiser_i
         if (in->cond_cache) sub.cond_cache = in->cond_cache + (size_t)lo * S * 768;
         sub.rows_hint = in->rows_hint * sub.B / in->B;            // estimates: proportional share
         sub.pairs_hint = in->pairs_hint * sub.B / in->B;
+        sub.rows_plan[0] = in->rows_plan[k];                      // (exact per group, or 0)
         const size_t bytes = align_up(plan(net, sub.B, S, E, w->dtype).total);
         hipStream_t sk = k == 0 ? s : g_split.aux[k - 1];
         if (k > 0 && (he = hipStreamWaitEvent(sk, g_split.fork, 0)) != hipSuccess) { rc = (int)he; break; }

@@ -865,8 +865,20 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         // Host-side view of the row count: exact without m_dev; with a device-side count the caller's estimate (rows_hint: the
         // drop-in modules count the valid tokens once per mask) or else the bound M.  It only chooses between "both kernels, the
         // device evaluates the rule" and "the 128 kernel alone, no rule" -- either is correct for any actual row count.
-        const int rows_est = (g.m_dev != nullptr && g.rows_hint > 0) ? (int)fmin((double)g.M, g.rows_hint + 0.5) : g.M;
+        // (rows_plan: the caller knows the device-side count exactly -- brepgen_hip.h)
+        const bool plan = g.m_dev != nullptr && g.rows_plan > 0;
+        const int rows_est = plan ? (int)fmin((double)g.M, g.rows_plan + 0.5)
+                                  : ((g.m_dev != nullptr && g.rows_hint > 0) ? (int)fmin((double)g.M, g.rows_hint + 0.5) : g.M);
         const int rows_hi = p256_rows(rows_est, g.N_pad / 256, split, hmode == 2);
+        if (plan && rows_hi >= rows_est) {
+            // every row panel of the planned count belongs to the 256 x 256 kernel: it runs ALONE over all the rows present (no rule, no
+            // tail kernel that would find nothing to do) -- correct for any actual count, like every other plan
+            gemm_cost(g, rows_all, fl, by);
+            ProfScope prof(split ? PK_GEMM_P256_SPLIT : PK_GEMM_P256, fl, by, s);
+            GemmArgs h = g;
+            if (split) h.p256_stagger = split_stagger(g);
+            return launch_p256<F16>(h, s);
+        }
         // (device-side row count: the partition is read from the table compact_rows wrote -- no table entry, no hybrid launch)
         const int ridx = p256_rule_index(g.N_pad / 256, split, hmode == 2);
         const bool can_tail = persistent_ok && (!g.stats_in || g.K == FOLD_PARTS * G_BK) &&

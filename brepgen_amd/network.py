@@ -264,41 +264,74 @@ class _HipDenoiser(nn.Module):
             class_label[uncond.to(class_label.device)] = 0
         return class_label.reshape(-1).to(device=device, dtype=torch.int64).contiguous()
 
-    def _row_hints(self, mask, S, E):
-        """(valid tokens, sum over samples of valid^2) of this mask -- the host-side ESTIMATE bg_denoiser_fwd takes (GEMM kernel
-        choice + profiler accounting; the kernels count the rows themselves).  Never a host synchronisation: a mask seen for the
-        first time is only remembered; the second call with the same tensor starts an asynchronous count (a few tiny kernels + a
-        copy into pinned memory behind an event) and still passes 0 = unknown; later calls use the count once the event has fired.
-        A caller that builds a fresh mask tensor every step (sample.py:197, 216: `mask.repeat(2, ...)`) therefore always runs with
-        the estimate 0 -- correct, bit-identical to the run with the estimate, and at no cost."""
-        if self.profile_hints:
-            return self.profile_hints
+    @staticmethod
+    def _group_ranges(B, ns):
+        """The contiguous sample groups of bg_denoiser_fwd's n_split (csrc/denoiser.hip: split_range)."""
+        ns = min(int(ns), 4)
+        if ns < 2 or B < ns:                               # (bg_denoiser_fwd: no split then)
+            ns = 1
+        base, rem = divmod(B, ns)
+        lo = 0
+        for k in range(ns):
+            hi = lo + base + (1 if k < rem else 0)
+            yield lo, hi
+            lo = hi
+
+    @staticmethod
+    def _slot_rows(lengths):
+        """64 x the number of slots compact.hip: pair_slots_kernel makes of these sample lengths (ascending order; the shortest
+        unpaired sample joins the longest one while their sum fits 64; samples without a valid token own no rows)."""
+        n = sorted(int(v) for v in lengths if v > 0)
+        i, j, slots = 0, len(n) - 1, 0
+        while i <= j:
+            if i < j and n[i] + n[j] <= 64:
+                i += 1
+            j -= 1
+            slots += 1
+        return 64 * slots
+
+    def _row_hints(self, mask, S, E, B, ns, paired):
+        """((valid tokens, sum over samples of valid^2), rows_plan) of this mask -- the host-side numbers bg_denoiser_fwd takes: the
+        ESTIMATE pair (GEMM kernel choice + profiler accounting) and, per sample group of the n_split, the EXACT row count the
+        kernels will see (valid tokens, or 64 x slots where the batch runs slot-packed: `paired`), which lets the launcher skip
+        launches that would find nothing to do.  The kernels always count the rows themselves.  Never a host synchronisation: a mask
+        seen for the first time is only remembered; the second call with the same tensor starts an asynchronous count (a few tiny
+        kernels + a copy into pinned memory behind an event) and still passes 0 = unknown; later calls use the count once the event
+        has fired.  A caller that builds a fresh mask tensor every step (sample.py:197, 216: `mask.repeat(2, ...)`) therefore always
+        runs with 0 -- correct, bit-identical to the run with the numbers, and at no cost."""
         if torch.cuda.is_current_stream_capturing():
-            return 0.0, 0.0
+            return (0.0, 0.0), ()
         key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.device)
         hc = self._hint_cache
         if hc.get("key") != key:
             # first sight of this mask: remember it, count nothing -- a caller that builds a fresh mask tensor every step pays no
-            # launch and no pinned allocation for an estimate it would never get to use
-            self._hint_cache = {"key": key, "event": None, "hints": None, "keep": mask}
-            return 0.0, 0.0
+            # launch and no pinned allocation for numbers it would never get to use
+            self._hint_cache = {"key": key, "event": None, "counts": None, "plans": {}, "keep": mask}
+            return (self.profile_hints or (0.0, 0.0)), ()
         if hc["event"] is None:
             # second call with the same tensor: the count is worth starting
-            valid = (~mask.reshape(mask.shape[0], -1).bool()).sum(1).double()
+            valid = (~mask.reshape(mask.shape[0], -1).bool()).sum(1).to(torch.int32)
             if self.NET == BG_EDGEPOS:                     # the mask marks faces, every valid face carries E edge tokens
                 valid = valid * E
-            host = torch.empty(2, dtype=torch.float64, pin_memory=True)
-            host.copy_(torch.stack([valid.sum(), (valid * valid).sum()]), non_blocking=True)
+            host = torch.empty(valid.numel(), dtype=torch.int32, pin_memory=True)
+            host.copy_(valid, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             # (the entry keeps the mask alive: its storage cannot be recycled for another mask while it is the key)
             hc["host"], hc["event"] = host, ev
-            return 0.0, 0.0
-        if hc["hints"] is None:
+            return (self.profile_hints or (0.0, 0.0)), ()
+        if hc["counts"] is None:
             if not hc["event"].query():
-                return 0.0, 0.0
-            hc["hints"] = (float(hc["host"][0]), float(hc["host"][1]))
-        return hc["hints"]
+                return (self.profile_hints or (0.0, 0.0)), ()
+            c = hc["host"].tolist()
+            hc["counts"] = c
+            hc["hints"] = (float(sum(c)), float(sum(v * v for v in c)))
+        pk = (int(ns), bool(paired))
+        if pk not in hc["plans"]:
+            c = hc["counts"]
+            hc["plans"][pk] = tuple(float(self._slot_rows(c[lo:hi]) if (paired and hi - lo <= 8192) else sum(c[lo:hi]))
+                                    for lo, hi in self._group_ranges(B, ns))
+        return (self.profile_hints or hc["hints"]), hc["plans"][pk]
 
     def _run(self, x, timesteps, surf_pos, surf_z, edge_pos, mask, class_label, B, S, E, out_shape):
         if not x.is_cuda:
@@ -324,11 +357,17 @@ class _HipDenoiser(nn.Module):
         # valid tokens / attention pairs of the batch: the host-side ESTIMATE the launcher uses to pick GEMM kernels (the device
         # still counts the rows itself) and what the opt-in profiler books; counted once per mask tensor (identity + version),
         # asynchronously -- 0 = unknown until the count has arrived
-        inp.rows_hint, inp.pairs_hint = self._row_hints(mask, S, E) if inp.varlen else (0.0, 0.0)
         ns = self.n_split
         if ns == "auto":
             ns = 2 if (B >= 2 and B * S * E >= 16384) else 1
         inp.n_split = int(ns)
+        (inp.rows_hint, inp.pairs_hint), plan = (0.0, 0.0), ()
+        if inp.varlen:
+            # (slot-packed execution: csrc/denoiser.hip slot_packing_applies + the LayerNorm-fold layers)
+            paired = self.NET == BG_SURFZ and dt != torch.float32 and bool(self.fold_layernorm) and S <= 64
+            (inp.rows_hint, inp.pairs_hint), plan = self._row_hints(mask, S, E, B, ns, paired)
+        for k in range(4):
+            inp.rows_plan[k] = plan[k] if k < len(plan) else 0.0
         # (never while a HIP graph is being captured: the flag would be baked into the graph, and a replay after the
         #  caller refreshed the static conditioning buffers through raw pointers would use stale embeds)
         use_cache = (self.cache_conditioning and surf_pos is not None and not self.training

@@ -264,6 +264,12 @@ typedef struct {
      * that drives several devices gets one set each), and used under a mutex (enqueue only). */
     int n_split;
     int _pad2;
+    /* Optional (variable-length execution; 0 = not known): the row count the kernels of sample group k WILL see -- the valid tokens of
+     * the group, or 64 x its slots where the batch runs slot-packed -- when the caller knows it exactly ([0] alone without n_split).
+     * Like rows_hint it only chooses between launch plans that are all correct for any actual count (the device still counts); what an
+     * exact count buys is launches that are not made: a GEMM whose rows all belong to the 256 x 256 kernel is ONE launch instead of that
+     * kernel + a 128 x 128 tail kernel that finds nothing to do (4-5 us each, twice per encoder layer on the face LDM's ragged loop). */
+    double rows_plan[4];
 } bg_denoiser_inputs;
 
 /* bytes of scratch bg_denoiser_fwd needs for these shapes (sized so that any n_split <= 4 fits) */

@@ -251,3 +251,37 @@ def test_split_pipe_gemm_vs_fp64(pc, dt, K):
     es = float(((r["stats"].cpu().double() - st).abs() / (1 + st.abs())).max())
     _record(f"split_pipe_vs_fp64_{str(dt)[6:]}_K{K}", {"hi_plus_lo_max_err": float(err.max()), "hi_mismatch_fraction": frac, "stats_rel": es})
     assert es < 2e-5, es
+
+
+def test_exact_row_plan_skips_nothing_but_launches(pc):
+    """rows_plan (the exact device-side row count, known to the module from its asynchronous count of the mask): the launcher may then
+    run a GEMM on the 256 x 256 kernel alone instead of that kernel + a 128 x 128 tail that finds nothing to do.  eps must not change,
+    with one and two sample groups, and the plan must equal what the device counted."""
+    from brepgen_amd import _lib
+    for ns in (1, 2):
+        m, _ = pc.build_net("SurfZNet", 6, False, BF16, varlen=True)
+        m.n_split = ns
+        args = [a.cuda() if torch.is_tensor(a) else a for a in pc.synth_inputs("SurfZNet", 512, 60, 1, False)]
+        with torch.no_grad():
+            first = m(*args).clone()                              # first sight of the mask: no numbers
+            second = m(*args).clone()                             # count started
+            torch.cuda.synchronize()
+            third = m(*args).clone()                              # count arrived: planned launches
+            with _lib.profile() as prof:
+                m(*args)
+        assert torch.equal(first, second) and torch.equal(first, third)
+        hc = m._hint_cache
+        assert hc["counts"] is not None and (ns, True) in hc["plans"]
+        counts = (~args[3]).sum(1).tolist()
+        assert hc["counts"] == counts
+        want = [m._slot_rows(counts[lo:hi]) for lo, hi in m._group_ranges(512, ns)]
+        assert list(hc["plans"][(ns, True)]) == [float(v) for v in want]
+        # the residual-stream GEMMs (24 per evaluation and group): where the rule gives every panel of the planned count to the
+        # 256 x 256 kernel it runs alone, where it gives it none the pipelined 128 x 128 kernel does -- never both
+        lib = _lib.load()
+        names = {r["kernel"]: r["launches"] for r in prof.rows}
+        all256 = [lib.bg_gemm_p256_rows(int(v), 768, 1, int(ns > 1)) >= v for v in want]
+        none256 = [lib.bg_gemm_p256_rows(int(v), 768, 1, int(ns > 1)) == 0 for v in want]
+        assert all(a or n for a, n in zip(all256, none256)), (want, "the test shape should not need both kernels")
+        assert names.get("gemm16_p256_kernel(256x256, split-residual launches)", 0) == 24 * sum(all256), names
+        assert names.get("gemm16_split_pipe_kernel(128x128)", 0) == 24 * sum(none256), names
