@@ -36,7 +36,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
 //  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEN_VARIANT = 0, TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -76,6 +76,11 @@ __device__ __forceinline__ uint2 pack4_16(float a, float b, float c, float d, in
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each) for results that are rounded to 16 bits next: the IEEE division of silu_f is
+// about ten VALU instructions per element, and the kernels that use this issue 768 of them per token (embed.hip, out_tail.hip)
+__device__ __forceinline__ float silu_rcp(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
 
 // XCD-aware bijective remap of a 1-D block id (MI355X: block b runs on XCD b % 8, each XCD has a private
 // 4 MiB L2).  Consecutive *logical* ids land on the same XCD back-to-back, so tiles that share an operand

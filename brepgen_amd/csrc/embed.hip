@@ -114,7 +114,10 @@ __global__ __launch_bounds__(512) void embed_ln_silu_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = silu_f((acc[t][r] - mean[r]) * rstd[r] * gcol[t] + bcol[t]);
+        for (int r = 0; r < 16; ++r) {
+            const float y = (acc[t][r] - mean[r]) * rstd[r] * gcol[t] + bcol[t];
+            acc[t][r] = OUT == BG_F32 ? silu_f(y) : silu_rcp(y);   // (fp32 output = the exact-fp32 mode: IEEE division; 16-bit: rounded next)
+        }
 
     if (OUT == BG_F32) {
         float* o = reinterpret_cast<float*>(out);

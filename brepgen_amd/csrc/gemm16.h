@@ -49,8 +49,4 @@ template <bool F16> int launch_p256(const GemmArgs& g, hipStream_t s);
 bool split_pipe_eligible(const GemmArgs& g);
 template <bool F16> int launch_split_pipe(const GemmArgs& g, hipStream_t s);
 
-// the same on a 256 x 128 tile with a three-slot ring, one workgroup per CU (gemm_split3.hip, round 5)
-bool split3_eligible(const GemmArgs& g);
-template <bool F16> int launch_split3(const GemmArgs& g, hipStream_t s);
-
 }  // namespace bg

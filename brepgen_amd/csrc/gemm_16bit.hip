@@ -809,20 +809,6 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
         return launch_status("gemm16");
     }
     const int nt = m128 * n128;
-    if (g_tune[TUNE_GEN_VARIANT] > 0 && g.cv_C == 0) {             // EXPERIMENT: ring depth / tile shape of the lock-step generic kernel
-        double fl, by;
-        gemm_cost(g, rows_all, fl, by);
-        ProfScope prof(PK_GEMM_BF16_64, fl, by, s);
-        const int m256 = (g.M + 255) / 256;
-        switch (g_tune[TUNE_GEN_VARIANT]) {
-            case 1: hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 3>), dim3(nt), dim3(256), 0, s, g); break;
-            case 2: hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 4>), dim3(nt), dim3(256), 0, s, g); break;
-            case 3: hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 3>), dim3(m256 * n128), dim3(512), 0, s, g); break;
-            case 4: hipLaunchKernelGGL((gemm16_kernel<F16, 256, 128, 4, 2, 2>), dim3(m256 * n128), dim3(512), 0, s, g); break;
-            default: hipLaunchKernelGGL((gemm16_kernel<F16, 128, 128, 2, 2, 2>), dim3(nt), dim3(256), 0, s, g); break;
-        }
-        return launch_status("gemm16(variant)");
-    }
     // Small launches (the reference's shipped batch of 16 samples: 960 face tokens -> 48 .. 144 tiles of 128 x 128 on 256 CUs): a
     // 128 x 128 tile per workgroup leaves most of the chip idle while every workgroup walks its 12 K-steps one DMA round trip at a
     // time.  64 x 64 tiles (two waves, 3-deep ring: two K-steps of DMA in flight) put four times as many workgroups on the chip
@@ -914,10 +900,6 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
     gemm_cost(g, rows_tail, fl_t, by_t);
     // residual-stream GEMMs of the encoder layers: the software-pipelined split kernel (gemm_split.hip) takes the rows the 256 x 256
     // kernel does not (bg_tune key 12 = 1: the 128 x 128 persistent kernel's split epilogue instead, for the bit-equality tests)
-    if ((g_tune[TUNE_SPLIT_PIPE] == 3 || g_tune[TUNE_SPLIT_PIPE] == 4) && split3_eligible(g_)) {    // (round 5: 256 x 128 tile, three-slot ring)
-        ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
-        return launch_split3<F16>(g_, s);
-    }
     if (g_tune[TUNE_SPLIT_PIPE] != 1 && split_pipe_eligible(g_)) {
         ProfScope prof(PK_GEMM_SPLIT, fl_t, by_t, s);
         return launch_split_pipe<F16>(g_, s);

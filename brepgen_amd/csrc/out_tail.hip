@@ -22,12 +22,6 @@ namespace bg {
 
 typedef __attribute__((ext_vector_type(4))) unsigned ot_u32x4;
 
-// x * sigmoid(x) with v_exp_f32 + v_rcp_f32 (1 ulp each; the value is rounded to 16 bits next): the IEEE division of silu_f is ten
-// VALU instructions per element, and this kernel issues 768 of them per token
-__device__ __forceinline__ float silu_rcp(float x) {
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-}
-
 template <bool F16, int NT>
 __global__ __launch_bounds__(512) void ln_silu_out_kernel(const void* __restrict__ t0, const float* __restrict__ gam,
                                                           const float* __restrict__ bet, const void* __restrict__ w3,
