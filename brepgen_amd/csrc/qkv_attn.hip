@@ -35,11 +35,13 @@
 // -mean rstd: two light steps each, behind the partner wave's MFMA segment).  In the last iteration of a tile (t+2) is K-step 0 of
 // the NEXT tile and nothing is staged into buffer 1: the seam costs no prologue (measured: 2.5-3.4 k of 36 k cycles before).
 //
-// Epilogue (all eight waves together): fold + bias + 16-bit rounding exactly as P_FOLD16, then q, k (row-major, the attention
-// kernel's swizzled K-tile layout) and v (transposed per sample, that kernel's V^T layout) go to LDS -- buffer 1 and the place of
-// the statistics, consumed by then; buffer 0 already holds the next tile's first K-step -- one barrier; every wave runs the
-// attention of 32 queries of one sample -- attn16_kernel's arithmetic (the 0 / -inf key bias only where a sub-tile holds dead
-// keys, no rescaling of the empty accumulator: neither changes a bit) -- and stores 32 x 64 outputs; one barrier.
+// Epilogue (all eight waves together): fold + bias + 16-bit rounding exactly as P_FOLD16, then q, k and v go to LDS row-major (one
+// 128-byte row per token slot, 16-byte chunks XOR-swizzled by the row: eight-byte stores straight from the accumulator quads) --
+// buffer 1 and the place of the statistics, consumed by then; buffer 0 already holds the next tile's first K-step -- one barrier;
+// every wave runs the attention of 32 queries of one sample -- attn16_kernel's arithmetic (the 0 / -inf key bias only where a
+// sub-tile holds dead keys, no rescaling of the empty accumulator: neither changes a bit), the V^T fragments of P V read with
+// ds_read_b64_tr_b16 (round 5; until then v was stored transposed with 64 two-byte LDS stores per wave) -- and stores 32 x 64
+// outputs, 16 bytes per lane after one v_permlane32_swap per register pair; one barrier.
 // Per tile (s_memtime, profiles/r04/qkv_attn_stamps_*.log): K loop 21 k cycles for 18.4 k cycles of MFMA issue per SIMD, fold +
 // images 3.5-4.8 k, attention 4.4-7 k (VALU-issue-bound: two waves per SIMD), barriers 1.5 + 2.6 k.
 // Results are bit-identical to gemm (P_FOLD16) + attention (tests/test_gpu_round4.py).
@@ -62,8 +64,7 @@ constexpr int QA_AUX = QA_RING, QA_BIAS = QA_LDS - QA_AUX - 2048, QA_CSUM = QA_B
 constexpr int QA_QIMG = QA_BUF, QA_KIMG = QA_QIMG + 32768, QA_VIMG = QA_KIMG + 32768;
 
 constexpr int QA_MB = QA_AUX + QA_BIAS - 1024;             // 256 floats: additive key bias (0 / -inf) of the tile's slots (key-padding mask given)
-static_assert(QA_VIMG + 8 * 64 * 36 * 2 <= QA_MB && QA_VIMG + 4 * 64 * 68 * 2 <= QA_MB, "the V^T image ends below the key bias");
-static_assert(QA_VIMG + 8 * 64 * 36 * 2 <= QA_AUX + QA_BIAS && QA_VIMG + 4 * 64 * 68 * 2 <= QA_AUX + QA_BIAS, "the V^T image ends below the bias / column sums");
+static_assert(QA_VIMG + 32768 <= QA_MB && QA_VIMG + 32768 <= QA_AUX + QA_BIAS, "the V image ends below the key bias / bias / column sums");
 
 struct QkvAttnArgs {
     const void* a;            // [M, 768] raw 16-bit residual rows (hi plane)
@@ -83,6 +84,8 @@ struct QkvAttnArgs {
     int pin = 0;              // 1: XCD-pinned tile walk (see the kernel)
 };
 
+typedef __attribute__((ext_vector_type(4))) short qa_v4s;
+
 __device__ __forceinline__ int qa_opaque(int x) {
     asm volatile("" : "+v"(x));
     return x;
@@ -96,13 +99,12 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
     using V4 = typename E::V4;
     constexpr int SPT = 256 / S;              // samples per tile
     constexpr int WPS = S / 32;               // waves (query blocks) per sample
-    constexpr int VS = S + 4;                 // V^T row stride in elements (68 / 36: odd multiples of 8 bytes -> conflict-free ds_read_b64)
     constexpr int LD = BG_D_MODEL;            // 768
     __shared__ __attribute__((aligned(16))) unsigned char lds[QA_LDS];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // (wm, wn): rows 64 wm .., columns 96 wn ..; waves w and w + 4 share a SIMD: one of them gets wn = 0 (q + half of k: 24 wide LDS
-    // stores in the epilogue), the other wn = 1 (half of k + v: the transposing 16-bit stores)
+    // (wm, wn): rows 64 wm .., columns 96 wn ..; waves w and w + 4 share a SIMD: one of them gets wn = 0 (q + half of k), the other
+    // wn = 1 (half of k + v)
     const int wm = wave >> 1, wn = (wave ^ (wave >> 2)) & 1;
     const int late = wave >> 2;               // waves 4-7 (rows 128-255) run one barrier behind
     static_assert(!PAIR || (S == 64 && !MASK), "slot-packed batches: 64-row slots, dead keys come from the slot descriptors");
@@ -279,11 +281,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (PAIR) {
-        // a sub-tile of a slot's second sample reads up to 60 V^T elements past its row -- the next row, the next slot, or, behind the
-        // last image, LDS nobody writes: stale bits there may be inf / NaN patterns, and 0 * inf is NaN
-        if (threadIdx.x < 32) reinterpret_cast<unsigned*>(lds + QA_VIMG + 4 * 64 * VS * 2)[threadIdx.x] = 0u;
-    }
     // ---- prologue of the first tile: buffer 0 complete, A of buffer 1 in flight (as if issued in phase 6) ----
     a_offsets(grp);
     stage_stats(grp); stage_cols(head);
@@ -354,7 +351,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
             pair_na = __builtin_amdgcn_readfirstlane(pair_na);
             pair_nb = __builtin_amdgcn_readfirstlane(pair_nb);
         }
-        const int pair_ob = (pair_na + 3) & ~3;
         float key_bias = 0.f;                                    // (MASK) slot threadIdx.x of the tile: requested now, written to LDS after the images
         if (MASK && threadIdx.x < 256) {
             const int smp = grp * SPT + (int)threadIdx.x / S, key = (int)threadIdx.x % S;
@@ -383,29 +379,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                     union { V4 v; uint2 u; T t[4]; } pk;
                     pk.v = E::pack4(v[0], v[1], v[2], v[3]);
                     const int R = wm * 64 + i * 32 + l31;         // token slot of the tile
-                    if (c3 < 2) {
-                        *reinterpret_cast<uint2*>(lds + QA_QIMG + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
-                    } else if (PAIR) {
-                        // slot row t -> V^T column: sample a's keys at [0, n_a), everything behind (sample b, then the clones) from the
-                        // 4-aligned column ob on; the <= 3 columns between and the columns behind the last row are filled with a
-                        // neighbour's (finite) value -- they are read as dead keys with p = 0
-                        const int t = R & 63, col = t < pair_na ? t : pair_ob + (t - pair_na);
-                        T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + wm * (64 * VS);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) vt[(d + e) * VS + col] = pk.t[e];
-                        if (t == pair_na - 1)
-                            for (int cc = pair_na; cc < pair_ob; ++cc)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) vt[(d + e) * VS + cc] = pk.t[e];
-                        if (t == 63)
-                            for (int cc = col + 1; cc < VS; ++cc)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) vt[(d + e) * VS + cc] = pk.t[e];
-                    } else {
-                        T* vt = reinterpret_cast<T*>(lds + QA_VIMG) + (R / S) * (64 * VS) + (R % S);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) vt[(d + e) * VS] = pk.t[e];
-                    }
+                    // q, k and v all row-major, one 128-byte row per token slot, 16-byte chunks XOR-swizzled by the row (v was a
+                    // transposed image until round 5: 64 ds_write_b16 per wave against these 16 ds_write_b64; the attention now
+                    // reads it with ds_read_b64_tr_b16, as attn16_long_kernel does)
+                    *reinterpret_cast<uint2*>(lds + QA_QIMG + c3 * 32768 + R * 128 + ((((d >> 3) ^ ((R >> 1) & 7))) << 4) + (d & 7) * 2) = pk.u;
                     if (DBG) {
                         const int smp = grp * SPT + R / S, tok = R % S;
                         if (PAIR ? grp * 256 + R < Mv : (smp < g.B && tok < g.N))
@@ -431,7 +408,16 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 const int h = hq;
                 const unsigned char* qimg = lds + QA_QIMG + (slot * S + qb * 32) * 128;
                 const unsigned char* ktile = lds + QA_KIMG + slot * S * 128;
-                const T* vt = reinterpret_cast<const T*>(lds + QA_VIMG) + slot * (64 * VS);
+                // V^T fragments straight from the row-major image by transpose reads: inside a 16-lane group, lane i supplies the address
+                // of key (i >> 2), head dimensions 4 (i & 3) .. + 3 and receives 4 consecutive keys of dimension i; group g covers
+                // dimensions 16 (g & 1) .. + 15 of the 32-wide tile and the keys of k-chunk g >> 1 = hq (attn.hip: attn16_long_kernel)
+                const unsigned char* vimg = lds + QA_VIMG + slot * S * 128;
+                const int gi = ln & 15, gg = ln >> 4;
+                const int v_key0 = 4 * (gg >> 1) + (gi >> 2);     // key inside a 16-key slice (second read: + 8)
+                int v_c16[2], v_b8;                               // 16-byte chunk of the lane's dimensions per 32-wide tile, byte inside it
+                v_b8 = ((gi & 3) * 4 & 7) * 2;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) v_c16[dt] = (dt * 32 + (gg & 1) * 16 + (gi & 3) * 4) >> 3;
                 const int sw = (l31 >> 1) & 7;
                 V8 qf[4];
 #pragma unroll
@@ -449,7 +435,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 for (int si = 0; si < (PAIR ? 2 : 1); ++si) {
                     const int cnt = PAIR ? (si == 0 ? pair_na : pair_nb) : g.N;
                     const int row0 = (PAIR && si == 1) ? pair_na : 0;        // the sample's first key row inside the slot ...
-                    const int col0 = (PAIR && si == 1) ? pair_ob : 0;        // ... and its first V^T column
                     const bool member = !PAIR || (in_b == (si == 1));
                     if (PAIR && __ballot(member) == 0ull) continue;          // uniform: none of the wave's queries is in this sample
 #pragma unroll
@@ -515,14 +500,17 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                             V8 pb;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) pb[e] = (T)s[8 * sl + e];
+                            // the 4 + 4 keys of the slice this lane's P values belong to (rows clamped to the slot: a dead key, p = 0)
+                            int r_lo = row0 + sub * 32 + 16 * sl + v_key0, r_hi = r_lo + 8;
+                            if (PAIR) { r_lo = r_lo < 63 ? r_lo : 63; r_hi = r_hi < 63 ? r_hi : 63; }
 #pragma unroll
                             for (int dt = 0; dt < 2; ++dt) {
-                                const T* vrow = vt + (dt * 32 + l31) * VS + col0 + sub * 32 + 16 * sl + 4 * h;
-                                const V4 lo = *reinterpret_cast<const V4*>(vrow);
-                                const V4 hi = *reinterpret_cast<const V4*>(vrow + 8);
-                                V8 va;
-                                va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
-                                va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+                                const unsigned char* pl = vimg + r_lo * 128 + ((v_c16[dt] ^ ((r_lo >> 1) & 7)) << 4) + v_b8;
+                                const unsigned char* ph = vimg + r_hi * 128 + ((v_c16[dt] ^ ((r_hi >> 1) & 7)) << 4) + v_b8;
+                                union { qa_v4s s4[2]; V8 v; } vau;
+                                vau.s4[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) qa_v4s*)pl);
+                                vau.s4[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) qa_v4s*)ph);
+                                const V8 va = vau.v;
                                 o[dt] = E::mfma(va, pb, o[dt]);
                             }
                         }
@@ -532,15 +520,23 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
                 const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
                 if (PAIR || tq < g.N) {
                     T* op = reinterpret_cast<T*>(g.out) + (size_t)(PAIR ? grp * 256 + slot * 64 + tq : smp * g.N + tq) * LD + head * 64;
+                    // a lane holds dimensions 8 g4 + 4 h .. + 3 of its query per quad g4: lanes l and l + 32 exchange one quad of every
+                    // pair (v_permlane32_swap) so that each owns 8 consecutive dimensions -> 4 stores of 16 bytes instead of 8 of 8
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int d = dt * 32 + 8 * g4 + 4 * h;
-                            V4 pk;
-                            pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
-                            pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
-                            *reinterpret_cast<V4*>(op + d) = pk;
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            union { V4 v; unsigned u[2]; } q0, q1;
+                            q0.v[0] = (T)(o[dt][8 * k2 + 0] * inv); q0.v[1] = (T)(o[dt][8 * k2 + 1] * inv);
+                            q0.v[2] = (T)(o[dt][8 * k2 + 2] * inv); q0.v[3] = (T)(o[dt][8 * k2 + 3] * inv);
+                            q1.v[0] = (T)(o[dt][8 * k2 + 4] * inv); q1.v[1] = (T)(o[dt][8 * k2 + 5] * inv);
+                            q1.v[2] = (T)(o[dt][8 * k2 + 6] * inv); q1.v[3] = (T)(o[dt][8 * k2 + 7] * inv);
+                            // swap: (q0 of the upper half) <-> (q1 of the lower half): lanes < 32 end with quads (2 k2, h = 0 | 1), lanes >= 32
+                            // with quads (2 k2 + 1, h = 0 | 1)
+                            const auto w0 = __builtin_amdgcn_permlane32_swap(q0.u[0], q1.u[0], false, false);
+                            const auto w1 = __builtin_amdgcn_permlane32_swap(q0.u[1], q1.u[1], false, false);
+                            const uint4 st16 = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+                            *reinterpret_cast<uint4*>(op + dt * 32 + 16 * k2 + 8 * h) = st16;
                         }
                 }
             }

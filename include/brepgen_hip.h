@@ -431,6 +431,8 @@ int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number 
  *   key 12  split-residual GEMMs of the encoder layers: 1 = the 128 x 128 persistent kernel instead of the pipelined one
  *   key 13  QKV + attention of short, equally long sequences: 1 = as two launches (GEMM, attention) instead of the fused kernel,
  *           2 = fused wherever eligible (the library's own choice leaves a nearly empty second round of tiles to the two launches)
+ *   key 14  tile walk of that fused kernel: 1 = plain (every XCD runs all 12 heads), 2 = XCD-pinned head halves wherever the grid
+ *           allows (the library's own choice: from two rounds of tiles on)
  *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off) */
 int bg_tune_set(int key, int value);
 
