@@ -248,3 +248,36 @@ def test_gemm_partition_rule_between_the_256_and_128_kernels():
     assert f(17280, 768, 1, 0) == 68 * 256 and f(30720, 768, 1, 0) == 0 and f(61440, 768, 1, 0) == 240 * 256
     assert f(138752, 768, 1, 0) == 510 * 256 and f(138752, 768, 1, 1) == 542 * 256 and f(40960, 768, 1, 1) == 0
     assert f(100, 768, 0, 0) == 0 and f(0, 2304, 0, 0) == 0                 # a few tiles: the 128 kernel (finer tiles fill more CUs)
+
+
+def test_host_side_row_plan_helpers():
+    """network._slot_rows restates compact.hip: pair_slots_kernel on the host (the exact slot-packed row count the launcher plans with);
+    network._group_ranges restates bg_denoiser_fwd's contiguous sample groups (csrc/denoiser.hip: split_range)."""
+    import random
+    from brepgen_amd.network import _HipDenoiser as H
+
+    def slots_reference(n):                                       # the kernel's walk, written out (tests/test_gpu_round4.py checks it on the device)
+        order = sorted(range(len(n)), key=lambda i: (n[i], i))
+        i, j, k = 0, len(n) - 1, 0
+        while i < len(n) and n[order[i]] == 0:
+            i += 1
+        while i <= j:
+            if i < j and n[order[i]] + n[order[j]] <= 64:
+                i += 1
+            j -= 1
+            k += 1
+        return 64 * k
+
+    rng = random.Random(7)
+    for _ in range(300):
+        n = [rng.randint(0, 64) for _ in range(rng.randint(1, 200))]
+        assert H._slot_rows(n) == slots_reference(n)
+    assert H._slot_rows([0, 0]) == 0 and H._slot_rows([64]) == 64 and H._slot_rows([32, 32, 32]) == 128
+    for B in (1, 2, 3, 5, 16, 511, 512, 513):
+        for ns in (0, 1, 2, 3, 4, 7):
+            groups = list(H._group_ranges(B, ns))
+            want = min(ns, 4) if (min(ns, 4) >= 2 and B >= min(ns, 4)) else 1
+            assert len(groups) == want and groups[0][0] == 0 and groups[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+            sizes = [hi - lo for lo, hi in groups]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
