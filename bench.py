@@ -427,7 +427,7 @@ def rank_local_extra(name, k=3):
 
 def pmc_traffic(kernel, launches_per_step):
     """Fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written
-    by tools/pmc_summary.py from `bench.py --steps 40 --warmup 3 --split 1` under --pmc FETCH_SIZE / WRITE_SIZE: (2 x FETCH_SIZE
+    by tools/pmc_summary.py from `bench.py --steps 20 --warmup 5 --split 1` under --pmc FETCH_SIZE / WRITE_SIZE: (2 x FETCH_SIZE
     + WRITE_SIZE) KiB averaged over that kernel's launches -- the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).
     A stored measurement is only comparable with this run's algorithmic bytes when it was taken on the same step mix: the file
     records the kernel's launches per step of ITS run, and a mismatch of more than 5 % with this run's returns None."""
