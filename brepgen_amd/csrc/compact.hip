@@ -97,47 +97,125 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(const uint8_t* __restric
 //   offsets[b]         first row of sample b in the slot-packed layout (samples without a valid token: 0, never used)
 //   offsets[B]         = 64 * n_slots, the device-side row count every kernel reads
 //   slot_desc[2 k]     n_a, slot_desc[2 k + 1] n_b of slot k;   slot_a[k] = sample a of slot k
+// LDS of pair_slots_kernel: [B] shorts sorted | [B] bytes len | [B] bytes slen | a region that holds the per-wave length histograms
+// of the ranking and afterwards pair_i [B] shorts | lim [B] shorts
+static inline size_t pair_slots_lds_bytes(int B) {
+    const size_t nw = (size_t)(B + 63) / 64, hist = nw * 66 * sizeof(short), walk = (size_t)4 * B;
+    return (size_t)4 * B + (hist > walk ? hist : walk);
+}
+
 __global__ __launch_bounds__(1024) void pair_slots_kernel(const int* __restrict__ counts, int B, int* __restrict__ offsets,
                                                           int* __restrict__ slot_desc, int* __restrict__ slot_a, int* __restrict__ rule) {
-    // [B] sample ids in ascending length, [B] slot -> rank of its second sample (or -1), [B] lengths, [B] lengths in ascending order
-    extern __shared__ unsigned char sh[];
-    short* sorted = reinterpret_cast<short*>(sh);
-    short* pair_i = sorted + B;
-    unsigned char* len = reinterpret_cast<unsigned char*>(pair_i + B);
-    unsigned char* slen = len + B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh[];
+    short* sorted = reinterpret_cast<short*>(sh);                 // [B] sample ids in ascending (length, index)
+    unsigned char* len = reinterpret_cast<unsigned char*>(sorted + B);
+    unsigned char* slen = len + B;                                // lengths in ascending order
+    short* region = reinterpret_cast<short*>(sh + (size_t)4 * B);
+    short* wh = region;                                           // [waves of 64 samples][66] length histogram -> exclusive prefix over the waves
+    short* pair_i = region;                                       // (after the ranking) slot -> rank of its second sample, or -1
+    short* lim = region + B;                                      // per rank: how many ranks may still pair with it (below)
+    __shared__ int cum[66];                                       // cum[v + 1] = samples of length <= v
     __shared__ int n_slots_sh;
-    for (int i = threadIdx.x; i < B; i += 1024) len[i] = (unsigned char)counts[i];
+    const int lane = threadIdx.x & 63;
+    const int nw = (B + 63) >> 6;
+    if (threadIdx.x < 66) cum[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < nw * 66; i += 1024) wh[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 1024) {
-        const int li = len[i];
-        int rank = 0;
-        for (int j = 0; j < B; ++j) rank += (len[j] < li) || (len[j] == li && j < i);
-        sorted[rank] = (short)i;
-        slen[rank] = (unsigned char)li;
+    // ---- stable counting rank: rank = #shorter + #equally long with a smaller index.  Inside a wave of 64 consecutive samples the
+    // equally long ones are found with seven ballots (one per bit of the length); across waves by a prefix over per-wave histograms.
+    // (Until round 5 every thread compared its sample with all B others: O(B^2) dependent LDS reads -- 40 us at B = 512, 4 ms at 8192.)
+    auto same_length_before = [&](int i, int& li) -> int {
+        li = i < B ? (int)len[i] : 127;                           // (no sample is 127 long: the lanes past B form their own group)
+        unsigned long long match = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const unsigned long long bal = __ballot((li >> b) & 1);
+            match &= ((li >> b) & 1) ? bal : ~bal;
+        }
+        const int before = __popcll(match & ((1ull << lane) - 1ull));
+        if (before == 0 && i < B) wh[(i >> 6) * 66 + li] = (short)__popcll(match);       // (first of its group: the wave's count of that length)
+        return before;
+    };
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + threadIdx.x;
+        if (i < B) {
+            const int c = counts[i];
+            len[i] = (unsigned char)c;
+            atomicAdd(&cum[c + 1], 1);
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        // the two-pointer walk is inherently serial, so it touches nothing but LDS and keeps the next length of either pointer
-        // loaded ahead of its use (slot k always takes rank B - 1 - k as its first sample); everything else is written out by all
-        // threads below.  (Round 4 walked it with global stores and dependent LDS reads in every iteration: 63 us at B = 512.)
-        int i = 0, j = B - 1, k = 0;
-        while (i < B && slen[i] == 0) ++i;                        // samples without a valid token own no rows
-        int li = i < B ? slen[i] : 0, li_next = i + 1 < B ? slen[i + 1] : 0;
-        int lj = j >= 0 ? slen[j] : 0, lj_next = j >= 1 ? slen[j - 1] : 0;
-        while (i <= j) {
-            const bool paired = i < j && li + lj <= 64;
-            pair_i[k] = paired ? (short)i : (short)-1;
-            if (paired) {
-                ++i;
-                li = li_next;
-                li_next = i + 1 < B ? slen[i + 1] : 0;
-            }
-            --j; ++k;
-            lj = lj_next;
-            lj_next = j >= 1 ? slen[j - 1] : 0;
+    for (int base = 0; base < B; base += 1024) {
+        int li;
+        (void)same_length_before(base + threadIdx.x, li);
+    }
+    if (threadIdx.x == 0)
+        for (int v = 1; v < 66; ++v) cum[v] += cum[v - 1];
+    __syncthreads();
+    if (threadIdx.x < 65) {                                       // exclusive prefix over the waves, per length
+        int run = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int t = wh[w * 66 + threadIdx.x];
+            wh[w * 66 + threadIdx.x] = (short)run;
+            run += t;
         }
-        n_slots_sh = k;
-        offsets[B] = 64 * k;
+    }
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int li = i < B ? (int)len[i] : 127;                 // (the same ballots again, without the histogram write)
+        unsigned long long match = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            const unsigned long long bal = __ballot((li >> b) & 1);
+            match &= ((li >> b) & 1) ? bal : ~bal;
+        }
+        if (i < B) {
+            const int rank = cum[li] + wh[(i >> 6) * 66 + li] + __popcll(match & ((1ull << lane) - 1ull));
+            sorted[rank] = (short)i;
+            slen[rank] = (unsigned char)li;
+        }
+    }
+    __syncthreads();                                              // (the histograms are consumed: their place becomes pair_i / lim)
+    // The walk: the longest unpaired sample (rank j, descending) takes the shortest unpaired one (rank i, ascending) while their sum
+    // fits 64 -- i < j and slen[i] <= 64 - slen[j], i.e. (the ranks are sorted) i < lim[j] = min(j, #samples of length <= 64 - slen[j]).
+    // lim[] does not depend on the walk, so it is computed by all threads, and the walk itself -- i += (i < lim[j]) -- is pure register
+    // arithmetic on batches of 64 preloaded limits.  (Round 4 walked it with global stores and dependent LDS reads per iteration.)
+    for (int j = threadIdx.x; j < B; j += 1024) {
+        const int c = cum[64 - slen[j] + 1];
+        lim[j] = (short)(j < c ? j : c);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // one wave, state in SCALAR registers: every lane fetches one limit of the next 64 ranks, the walk reads them back with
+        // v_readlane and records its pairings in a 64-bit scalar mask, from which every lane derives the answer of its slot (a
+        // single-lane VALU walk costs ~230 cycles per slot)
+        int i = __builtin_amdgcn_readfirstlane(cum[1]), j = B - 1, k = 0;   // samples without a valid token (the first cum[1] ranks) own no rows
+        while (i <= j) {
+            const int jj = j - lane;
+            const int lv = jj >= 0 ? (int)lim[jj] : 0;
+            const int i0 = i;
+            int n = 0;
+            unsigned long long pm = 0ull;                         // bit u: slot k + u got a second sample
+#pragma unroll
+            for (int u = 0; u < 64; ++u) {
+                const int m = __builtin_amdgcn_readlane(lv, u);
+                const bool live = i <= j;                         // (once false it stays false: i never decreases, j only does)
+                const bool paired = live && i < m;
+                pm |= (unsigned long long)(paired ? 1 : 0) << u;
+                i += paired ? 1 : 0;
+                j -= live ? 1 : 0;
+                n += live ? 1 : 0;
+            }
+            // slot k + lane: paired -> the rank it took = i0 + the number of pairings before it in this batch
+            const int res = ((pm >> lane) & 1ull) ? i0 + __popcll(pm & ((1ull << lane) - 1ull)) : -1;
+            if (lane < n) pair_i[k + lane] = (short)res;
+            k += n;
+        }
+        if (lane == 0) {
+            n_slots_sh = k;
+            offsets[B] = 64 * k;
+        }
     }
     __syncthreads();
     const int n_slots = n_slots_sh;
@@ -175,7 +253,7 @@ int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, in
                         int* counts, hipStream_t s, int* rule) {
     ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * 6.0, s);
     hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, counts);
-    hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), (size_t)6 * B, s, counts, B, offsets, slot_desc, slot_a, rule);
+    hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), pair_slots_lds_bytes(B), s, counts, B, offsets, slot_desc, slot_a, rule);
     hipLaunchKernelGGL(fill_rows_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, offsets, src_row);
     hipLaunchKernelGGL(fill_clones_kernel, dim3(B), dim3(64), 0, s, offsets + B, slot_desc, src_row);
     return launch_status("compact_rows_paired");
