@@ -329,12 +329,10 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                 // way back a lane owns 8 consecutive columns of a row, so the residual arrives and hi / lo leave as 16-byte
                 // accesses of whole 128-byte lines, and one 8-lane butterfly gives the row's (sum, sum of squares) -- the
                 // arithmetic, its order and the statistics layout of the 128 x 128 kernel (gemm_16bit.hip), bit for bit.
-                // The residual loads are waited for with an explicit vmcnt(0) BEFORE the first store that follows them: the
-                // vector-memory counter is shared by loads and stores and the two classes retire out of order with respect to each
-                // other (a counted wait with younger stores passed early under load: measured, profiles/r03/gemm_p256_split_*.log),
-                // so a wave can only wait for a load issued after a store by waiting for that store as well.  Hence three batches
-                // (slabs 0-2, 3-5, 6-7: 48 registers in flight, the most that fits beside the accumulators without spilling) --
-                // three exposed waits per tile instead of one per slab.
+                // The vector-memory counter is shared by loads and stores and the two classes retire out of order with respect to each
+                // other (a counted wait that allowed younger STORES to stay in flight passed early under load: measured,
+                // profiles/r03/gemm_p256_split_*.log).  Until round 5 the loads were therefore waited for with vmcnt(0) in three
+                // batches (slabs 0-2, 3-5, 6-7); see the rotating set below for what replaced that.
                 const int k8 = ln & 7, r8 = ln >> 3;
                 float4 bias0 = zero4, bias1 = zero4;
                 if (has_bias) {
@@ -344,24 +342,31 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                 const unsigned char* rh = reinterpret_cast<const unsigned char*>(g.res_hi);
                 const unsigned char* rl = reinterpret_cast<const unsigned char*>(g.res_lo);
                 const unsigned col_b = (unsigned)(cbase + k8 * 8) * 2u;
-                u32x4 rbuf[8][2][2];                                  // [slab][it][hi / lo]; at most 3 slabs are live at a time (2 ahead)
+                // Round 5: the residual octets arrive through inline-asm loads into a ROTATING set of three slabs (48 registers, as
+                // before), and the waits are counted in LOADS: slab t has landed when at most the loads issued after it are
+                // outstanding (vmcnt(4 x slabs requested behind it)).  Loads retire in order among themselves; the stores of
+                // earlier slabs share the counter, but a pending store can only make such a wait longer, never let it pass early
+                // (round 3's wrong variant counted the stores as "may stay in flight").  The request for slab t + 3 goes out right
+                // behind slab t's stores, so two slabs' loads travel while a third is finished and stored -- no vmcnt(0) drain inside
+                // a tile's epilogue any more (there were three).  hipcc does not see these loads: nothing it inserts can drain them.
+                u32x4 rbuf[3][2][2];                                  // [slab % 3][it][hi / lo]
+                auto load16 = [&](u32x4& dst, const unsigned char* base, unsigned off) {
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(off), "s"(base) : "memory");
+                };
                 auto res_issue = [&](int t) {
 #pragma unroll
                     for (int it = 0; it < 2; ++it) {
                         int grow = rbase + t * 16 + it * 8 + r8;
                         grow = grow < Mv ? grow : Mv - 1;
                         const unsigned voff = (unsigned)grow * (unsigned)g.ld_res * 2u + col_b;
-                        // (compiler-visible loads: hipcc knows the destinations are pending and adds its own wait in front of
-                        //  res_wait's register pins -- after the explicit vmcnt(0) there, where it costs nothing)
-                        rbuf[t][it][0] = *reinterpret_cast<const u32x4*>(rh + voff);
-                        rbuf[t][it][1] = *reinterpret_cast<const u32x4*>(rl + voff);
+                        load16(rbuf[t % 3][it][0], rh, voff);
+                        load16(rbuf[t % 3][it][1], rl, voff);
                     }
                 };
-                auto res_wait = [&](int t0, int t1) {                // every load issued so far has landed (slabs t0 .. t1 - 1)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int t = t0; t < t1; ++t)                     // (pins the destination registers behind the wait)
-                        asm volatile("" : "+v"(rbuf[t][0][0]), "+v"(rbuf[t][0][1]), "+v"(rbuf[t][1][0]), "+v"(rbuf[t][1][1]) :: "memory");
+                auto res_wait = [&](int t, auto younger_c) {          // slab t has landed; `younger` slabs were requested after it
+                    constexpr int YOUNGER = decltype(younger_c)::value;
+                    wait_vmcnt<4 * YOUNGER>();
+                    asm volatile("" : "+v"(rbuf[t % 3][0][0]), "+v"(rbuf[t % 3][0][1]), "+v"(rbuf[t % 3][1][0]), "+v"(rbuf[t % 3][1][1]) :: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 T* out_lo = reinterpret_cast<T*>(g.out_lo);
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                         }
-                        const u32x4 h4 = rbuf[t][it][0], l4 = rbuf[t][it][1];
+                        const u32x4 h4 = rbuf[t % 3][it][0], l4 = rbuf[t % 3][it][1];
                         float fh[4], fl[4];
                         unpack4_16<F16>(make_uint2(h4[0], h4[1]), fh);
                         unpack4_16<F16>(make_uint2(l4[0], l4[1]), fl);
@@ -424,17 +429,18 @@ __global__ __launch_bounds__(512) void gemm16_p256_kernel(GemmArgs g) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 };
+                using Y0 = std::integral_constant<int, 0>;
+                using Y1 = std::integral_constant<int, 1>;
+                using Y2 = std::integral_constant<int, 2>;
                 res_issue(0); res_issue(1); res_issue(2);
-                res_wait(0, 3);
-                slab(0); slab(1); slab(2);
-                __builtin_amdgcn_sched_barrier(0);
-                res_issue(3); res_issue(4); res_issue(5);
-                res_wait(3, 6);
-                slab(3); slab(4); slab(5);
-                __builtin_amdgcn_sched_barrier(0);
-                res_issue(6); res_issue(7);
-                res_wait(6, 8);
-                slab(6); slab(7);
+                res_wait(0, Y2{}); slab(0); res_issue(3);
+                res_wait(1, Y2{}); slab(1); res_issue(4);
+                res_wait(2, Y2{}); slab(2); res_issue(5);
+                res_wait(3, Y2{}); slab(3); res_issue(6);
+                res_wait(4, Y2{}); slab(4); res_issue(7);
+                res_wait(5, Y2{}); slab(5);
+                res_wait(6, Y1{}); slab(6);
+                res_wait(7, Y0{}); slab(7);
             } else {
                 // a lane's 32 columns are cbase + j*32 + 8*q + 4*hq + e (q, e = 0..3), i.e. 8 float4 of bias (LayerNorm fold: and of
                 // column sums, plus the (rstd, -mean rstd) pairs of its four rows) -- read before the first pass overwrites the patch
