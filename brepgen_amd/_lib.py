@@ -133,6 +133,8 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES)
 
+ABI_VERSION = 5          # BG_ABI_VERSION of include/brepgen_hip.h this binding was written against
+
 _lib = None
 
 
@@ -152,7 +154,7 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export the ABI
             fn.restype, fn.argtypes = res, args
-        if lib.bg_abi_version() != 5:
+        if lib.bg_abi_version() != ABI_VERSION:
             raise BrepgenHipError("libbrepgen_hip.so ABI version mismatch")
         for kv in filter(None, os.environ.get("BG_TUNE", "").split(",")):     # A/B knobs, e.g. BG_TUNE="0=10,5=1"
             k, v = kv.split("=")

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/brepgen_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTS)
-    assert lib.bg_abi_version() == 5
+    assert lib.bg_abi_version() == _lib.ABI_VERSION
 
 
 def test_argument_errors_are_negative_and_explained():
@@ -281,3 +281,14 @@ def test_host_side_row_plan_helpers():
             assert all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
             sizes = [hi - lo for lo, hi in groups]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_driver_entry_build_runs():
+    """__graft_entry__.build() is what the driver runs on CPU every round: it must agree with the header's ABI version (a stale literal
+    there once survived an ABI bump) and resolve every export."""
+    import re
+    import __graft_entry__ as entry
+    from brepgen_amd import _lib
+    entry.build()
+    header = open(os.path.join(ROOT, "include", "brepgen_hip.h")).read()
+    assert int(re.search(r"#define BG_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION

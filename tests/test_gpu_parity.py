@@ -29,7 +29,7 @@ def pc():
 def test_native_library_is_loaded(pc):
     from brepgen_amd import _lib
     lib = _lib.load()
-    assert lib.bg_abi_version() == 5
+    assert lib.bg_abi_version() == _lib.ABI_VERSION
     maps = open("/proc/self/maps").read()
     assert "libbrepgen_hip.so" in maps
 
