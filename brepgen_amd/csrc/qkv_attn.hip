@@ -43,13 +43,14 @@
 // ds_read_b64_tr_b16 (round 5; until then v was stored transposed with 64 two-byte LDS stores per wave) -- and stores 32 x 64
 // outputs, 16 bytes per lane after one v_permlane32_swap per register pair; one barrier.
 // Per tile (s_memtime, profiles/r04/qkv_attn_stamps_*.log): K loop 21 k cycles for 18.4 k cycles of MFMA issue per SIMD, fold +
-// images 3.5-4.8 k, attention 4.4-7 k (VALU-issue-bound: two waves per SIMD), barriers 1.5 + 2.6 k.
+// images 3.5-4.8 k, attention 4.4-7 k (VALU-issue-bound: two waves per SIMD), barriers 1.5 + 2.6 k -- round 4's stamps; round 5's
+// epilogue (row-major v, transpose reads, 16-byte stores) took 4.5 % off the launch (profiles/r05/qkv_attn_v_row_major_*.log).
 // Results are bit-identical to gemm (P_FOLD16) + attention (tests/test_gpu_round4.py).
 //
 // Ragged batches (PAIR; SurfZNet's variable-length execution): the rows arrive SLOT-PACKED (compact.hip: compact_rows_paired) --
 // every 64-row slot holds one or two whole samples and clones of its first row, *m_dev rows exist, slot_desc gives (n_a, n_b) per
-// slot.  Tile rows are then consecutive global rows; in the epilogue v goes to the slot's V^T image with sample b from a
-// 4-column-aligned offset on, and a wave walks the keys of each of its (at most two) samples from that sample's own first key;
+// slot.  Tile rows are then consecutive global rows, and a wave walks the keys of each of its (at most two) samples from that
+// sample's own first key (K and V rows at any offset inside the slot: both images are row-major, rows clamped to the slot's 64);
 // a lane of the other sample sees -inf scores, which makes its online-softmax update an exact no-op -- so every valid token ends
 // with the bits attn16_kernel produces on the dense packing.  The K loop is the same.
 #include "gemm16.h"
