@@ -292,3 +292,32 @@ def test_driver_entry_build_runs():
     entry.build()
     header = open(os.path.join(ROOT, "include", "brepgen_hip.h")).read()
     assert int(re.search(r"#define BG_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """Every struct of include/brepgen_hip.h that brepgen_amd/_lib.py mirrors: sizeof and the offset of every field, as gcc lays the
+    header out, against ctypes -- the check a maintainer of another binding would run after an ABI bump."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    pairs = {"bg_mlp_weights": _lib.MlpWeights, "bg_layer_weights": _lib.LayerWeights, "bg_denoiser_weights": _lib.DenoiserWeights,
+             "bg_denoiser_inputs": _lib.DenoiserInputs, "bg_gemm_desc": _lib.GemmDesc, "bg_conv_desc": _lib.ConvDesc,
+             "bg_vae_op": _lib.VaeOp, "bg_profile_row": _lib.ProfileRow}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "brepgen_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'    printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'    printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['    return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr                            # (a field _lib.py names that the header does not have fails HERE)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
+        for fname, *_ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
