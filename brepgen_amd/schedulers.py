@@ -74,7 +74,30 @@ class DDPMScheduler:
         self.betas, self.alphas_cumprod = _alphas_cumprod(num_train_timesteps, beta_start, beta_end, beta_schedule)
         self._acp = self.alphas_cumprod.numpy().astype(np.float32)
         self.num_inference_steps = None
-        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self._set_schedule(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64), None)
+
+    def _set_schedule(self, ts, device):
+        self._host_ts, self._cursor = [int(v) for v in ts], 0
+        self.timesteps = torch.from_numpy(ts).to(device)
+
+    def _timestep(self, timestep):
+        """The step's timestep as a host integer WITHOUT a device synchronisation.  A caller that follows the reference
+        literally iterates `scheduler.timesteps.cuda()` and passes 0-d device tensors: `int()` of one would stall the host on
+        everything enqueued so far, at every step.  The schedule is host state (set_timesteps built it), so a device timestep is
+        taken from it by position -- the steps of a schedule are consumed in order, as sample.py:126-202 does, and the cursor
+        wraps for the next sampling run; a host timestep (int / CPU tensor) is used as given and re-seats the cursor."""
+        if torch.is_tensor(timestep) and timestep.device.type != "cpu":
+            t = self._host_ts[self._cursor % len(self._host_ts)]
+            self._cursor += 1
+            return t
+        t = int(timestep)
+        n = len(self._host_ts)
+        c = self._cursor % n
+        if self._host_ts[c] == t:
+            self._cursor = c + 1
+        elif t in self._host_ts:
+            self._cursor = self._host_ts.index(t) + 1
+        return t
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -87,7 +110,7 @@ class DDPMScheduler:
         ratio = T // num_inference_steps
         ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
         ts += self.config.steps_offset
-        self.timesteps = torch.from_numpy(ts).to(device)
+        self._set_schedule(ts, device)
 
     def _coefficients(self, t):
         T = self.config.num_train_timesteps
@@ -107,7 +130,7 @@ class DDPMScheduler:
                     sigma=sigma)
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=True, *, noise=None, guidance=None):
-        t = int(timestep)
+        t = self._timestep(timestep)
         x = _prep(sample)
         eps_c, eps_u, w = _split_guidance(_prep(model_output), x, guidance)
         c = self._coefficients(t)
@@ -164,6 +187,7 @@ class PNDMScheduler:
         self.num_inference_steps = None
         self._reset()
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self._host_ts = [int(v) for v in self.timesteps]
         self.prk_timesteps = np.array([], dtype=np.int64)
 
     def _reset(self):
@@ -186,6 +210,7 @@ class PNDMScheduler:
         self.plms_timesteps = _t[:-3][::-1].copy()
         ts = np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)
         self.timesteps = torch.from_numpy(ts).to(device)
+        self._host_ts = [int(v) for v in ts]
         self._reset()
 
     def _prev_coeffs(self, t, prev_t):
@@ -199,7 +224,12 @@ class PNDMScheduler:
     def step(self, model_output, timestep, sample, return_dict=True, *, guidance=None):
         if self.num_inference_steps is None:
             raise ValueError("call set_timesteps first")
-        t = int(timestep)
+        if torch.is_tensor(timestep) and timestep.device.type != "cpu":
+            # no device synchronisation (see DDPMScheduler._timestep): PNDM is stateful anyway -- evaluation number `counter` of the
+            # schedule IS timesteps[counter], as upstream's own step_prk / step_plms assume
+            t = self._host_ts[self.counter % len(self._host_ts)]
+        else:
+            t = int(timestep)
         x = _prep(sample)
         eps_c, eps_u, w = _split_guidance(_prep(model_output), x, guidance)
         ratio = self.config.num_train_timesteps // self.num_inference_steps

@@ -221,3 +221,71 @@ def seeded_state_dict(net, seed, use_cf=False):
         else:                                    # any bias
             sd[key] = 0.02 * torch.randn(shape, generator=g)
     return sd
+
+
+STRESS_OUTLIER_CHANNELS = (77, 500)
+STRESS_KINDS = ("outlier", "offset")
+
+
+def stress_state_dict(net, seed, use_cf=False, kind="outlier"):
+    """Hostile synthetic weights: the statistics trained transformers show and `seeded_state_dict` does not.
+
+    Both kinds:
+    * LayerNorm gains log-normal in [0.05, 5] (median 1), LayerNorm biases ~ N(0, 1);
+    * matrices heavy-tailed: Student-t with 3 degrees of freedom (clamped at 12 sigma), scaled to variance 1/fan_in
+      (a few entries per row are 5-10 x the rest).
+    kind = "outlier": two OUTLIER CHANNELS (`STRESS_OUTLIER_CHANNELS`): the rows of every input embed's second Linear
+      that feed them are 100 x the others, so the residual stream enters layer 0 with two channels ~ 100 x its typical
+      magnitude (the "massive activation" pattern), and out_proj / linear2 write 10 x into the same channels.
+    kind = "offset": rows whose mean is ~ 10 x their standard deviation: the time embed's output bias carries a
+      constant of 25 and the matrices that write the residual stream are halved, so that |row mean| stays 5-12 x the
+      row's spread through the twelve layers -- the regime in which a LayerNorm FOLD
+      (rstd * (x W'^T) - mean * rstd * colsum(W')) cancels two large terms instead of normalising first.
+    (The two cannot share one net: the outlier channels ARE the row's standard deviation.)
+
+    Drawn key by key in `state_dict_spec` order from one CPU generator, like `seeded_state_dict`."""
+    assert kind in STRESS_KINDS
+    g = torch.Generator().manual_seed(seed)
+    c0, c1 = STRESS_OUTLIER_CHANNELS
+    sd = {}
+
+    def student_t3(shape):
+        z = torch.randn(shape, generator=g)
+        chi = (torch.randn((3,) + tuple(shape), generator=g) ** 2).sum(0) / 3.0
+        return z / torch.sqrt(chi) / math.sqrt(3.0)           # Var[t_3] = 3
+
+    for key, shape in state_dict_spec(net, use_cf).items():
+        if key == "class_embed.embed.weight":
+            sd[key] = torch.randn(shape, generator=g) * 0.05
+        elif len(shape) == 2:
+            w = student_t3(shape).clamp(-12, 12) * (1.0 / math.sqrt(shape[1]))
+            embed_out = key.endswith(".3.weight") and not key.startswith(("fc_out", "time_embed"))
+            writes_stream = key.endswith("out_proj.weight") or key.endswith("linear2.weight")
+            if kind == "outlier":
+                if embed_out:
+                    w[c0] *= 100.0
+                    w[c1] *= 100.0
+                if writes_stream:
+                    w[c0] *= 10.0
+                    w[c1] *= 10.0
+            elif writes_stream:
+                w *= 0.5
+            sd[key] = w
+        elif key.endswith("weight"):            # LayerNorm gain
+            sd[key] = torch.exp(0.8 * torch.randn(shape, generator=g)).clamp(0.05, 5.0)
+        elif ".1.bias" in key or "norm" in key:  # LayerNorm bias
+            sd[key] = torch.randn(shape, generator=g)
+        else:                                    # Linear bias
+            b = 0.1 * torch.randn(shape, generator=g)
+            if kind == "offset" and key == "time_embed.3.bias":
+                b = b + 25.0
+            sd[key] = b
+    return sd
+
+
+def make_state_dict(weights, net, seed, use_cf=False):
+    """`weights`: "seeded" | "stress_outlier" | "stress_offset" (the MANIFEST's field)."""
+    if weights == "seeded":
+        return seeded_state_dict(net, seed, use_cf)
+    assert weights.startswith("stress_")
+    return stress_state_dict(net, seed, use_cf, kind=weights[len("stress_"):])

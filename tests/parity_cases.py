@@ -241,10 +241,10 @@ NETS = {"SurfPosNet": bga.SurfPosNet, "SurfZNet": bga.SurfZNet, "EdgePosNet": bg
 MANIFEST = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
 
 
-def build_net(net, seed, use_cf, dtype, varlen=False):
+def build_net(net, seed, use_cf, dtype, varlen=False, weights="seeded"):
     """varlen=False: dense execution (every position as the reference computes it) -- what the position-exact parity
     tests check; varlen=True: the product default (valid tokens only, 0 at padded positions)."""
-    sd = orc.seeded_state_dict(net, seed, use_cf)
+    sd = orc.make_state_dict(weights, net, seed, use_cf)
     m = NETS[net](use_cf)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
@@ -253,17 +253,32 @@ def build_net(net, seed, use_cf, dtype, varlen=False):
     return m, sd
 
 
-def golden_case(name, dtype, varlen=False):
-    """HIP denoiser vs the golden output written by the reference's own class (tests/golden/gen_golden.py)."""
+def golden_case(name, dtype, varlen=False, fold=True, center=True, autocast_ref=False):
+    """HIP denoiser vs the golden output written by the reference's own class (tests/golden/gen_golden.py).
+    autocast_ref: also run oracle/ref_formulation.py (the reference's formulation: stock nn.TransformerEncoder) under
+    torch.autocast('cuda', dtype) on the same inputs -- how sample.py:121 runs the reference -- and report its error."""
     meta = MANIFEST["cases"][name]
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     args = [torch.from_numpy(z[k]).to(DEV) if k in z.files else None for k in meta["args"]]
-    m, _ = build_net(meta["net"], meta["weight_seed"], meta["use_cf"], dtype, varlen)
+    m, sd = build_net(meta["net"], meta["weight_seed"], meta["use_cf"], dtype, varlen, meta.get("weights", "seeded"))
+    m.fold_layernorm, m.center_stream = fold, center
     with torch.no_grad():
         got = m(*args)
     want = torch.from_numpy(z["out"])
     e = _err(got, want)
     e["got"] = got.cpu()
+    mk = "surf_mask" if "surf_mask" in meta["args"] else ("mask" if "mask" in meta["args"] else None)
+    vsel = ~torch.from_numpy(z[mk]) if mk is not None else torch.ones(want.shape[:-1], dtype=torch.bool)
+    if meta["net"] == "EdgePosNet" and mk is not None:
+        vsel = vsel.unsqueeze(-1).expand(want.shape[:-1])
+    e["mean_abs_valid"] = float((got.cpu() - want)[vsel].abs().mean())
+    if autocast_ref:
+        from oracle import ref_formulation as rf
+        ref = rf.build(meta["net"], sd, meta["use_cf"]).to(DEV)
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            ra = ref(*args).float().cpu()
+        e["autocast_max_abs_valid"] = float((ra - want)[vsel].abs().max())
+        e["autocast_mean_abs_valid"] = float((ra - want)[vsel].abs().mean())
     mask_key = "surf_mask" if "surf_mask" in meta["args"] else ("mask" if "mask" in meta["args"] else None)
     if mask_key is not None and meta["net"] != "EdgePosNet":
         valid = ~torch.from_numpy(z[mask_key])

@@ -321,3 +321,25 @@ def test_ctypes_structs_match_the_header(tmp_path):
         assert int(out[cname]) == C.sizeof(cls), (cname, out[cname], C.sizeof(cls))
         for fname, *_ in cls._fields_:
             assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_scheduler_step_takes_a_device_timestep_without_reading_it():
+    """sample.py iterates `scheduler.timesteps` -- on the device if the caller moved them there -- and hands each 0-d tensor to
+    step(): `int()` of a device tensor is a synchronisation per step.  The schedule is host state, so the product takes a device
+    timestep from it by position.  A `meta` tensor stands in for the device tensor here: reading it would raise."""
+    import torch
+    from brepgen_amd.schedulers import DDPMScheduler, PNDMScheduler
+    d = DDPMScheduler(num_train_timesteps=1000)
+    d.set_timesteps(1000)
+    dev_t = torch.empty((), dtype=torch.int64, device="meta")
+    assert [d._timestep(dev_t) for _ in range(3)] == [999, 998, 997]
+    assert d._timestep(torch.tensor(500)) == 500 and d._timestep(dev_t) == 499      # a host timestep re-seats the cursor
+    assert d._timestep(7) == 7 and d._timestep(dev_t) == 6
+    d.set_timesteps(50)
+    assert [d._timestep(dev_t) for _ in range(2)] == [980, 960]
+    for _ in range(48):
+        d._timestep(dev_t)
+    assert d._timestep(dev_t) == 980                                                 # wraps for the next sampling run
+    p = PNDMScheduler(num_train_timesteps=1000)
+    p.set_timesteps(200)
+    assert p._host_ts[:5] == [int(v) for v in p.timesteps[:5]] and len(p._host_ts) == 209

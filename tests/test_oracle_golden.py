@@ -23,12 +23,13 @@ def load_case(name):
 @pytest.mark.parametrize("name", sorted(MANIFEST["cases"]))
 def test_oracle_matches_reference_golden(name):
     meta, args, want = load_case(name)
-    sd = orc.seeded_state_dict(meta["net"], meta["weight_seed"], meta["use_cf"])
+    sd = orc.make_state_dict(meta.get("weights", "seeded"), meta["net"], meta["weight_seed"], meta["use_cf"])
     with torch.no_grad():
         got = orc.FORWARD[meta["net"]](sd, *args)
     assert got.shape == want.shape
-    # fp32 summation-order noise only (recorded 1.3e-6 .. 2.2e-6 at generation time)
-    assert float((got - want).abs().max()) < 1e-5
+    # fp32 summation-order noise only (recorded 1.3e-6 .. 2.2e-6 at generation time; the hostile-weight cases, whose residual
+    # stream reaches |x| ~ 900, 2.6e-6 .. 3.5e-5: MANIFEST.json) -- relative to the output's magnitude
+    assert float((got - want).abs().max()) < 1e-5 * max(1.0, meta["out_absmax"])
 
 
 def test_state_dict_spec_counts():
@@ -43,7 +44,7 @@ def test_state_dict_spec_counts():
 def test_masked_keys_do_not_influence_valid_tokens():
     """Padded tokens are excluded as keys (network.py:1196): changing them must not move valid outputs."""
     meta, args, want = load_case("surfz_b3_n60")
-    sd = orc.seeded_state_dict(meta["net"], meta["weight_seed"], meta["use_cf"])
+    sd = orc.make_state_dict(meta.get("weights", "seeded"), meta["net"], meta["weight_seed"], meta["use_cf"])
     surfZ, t, surfPos, mask, cl = args
     z2 = surfZ.clone()
     z2[mask] = 123.0
@@ -63,10 +64,10 @@ def test_reference_formulation_matches_reference_golden(name):
     CPU-baseline formulation) loads the reference-keyed weights strictly and reproduces the reference's own outputs."""
     from oracle import ref_formulation as rf
     meta, args, want = load_case(name)
-    sd = orc.seeded_state_dict(meta["net"], meta["weight_seed"], meta["use_cf"])
+    sd = orc.make_state_dict(meta.get("weights", "seeded"), meta["net"], meta["weight_seed"], meta["use_cf"])
     m = rf.build(meta["net"], sd, meta["use_cf"])
     with torch.no_grad():
         got = m(*args)
     assert got.shape == want.shape
     valid = torch.isfinite(want)
-    assert float((got - want)[valid].abs().max()) < 1e-5
+    assert float((got - want)[valid].abs().max()) < 1e-5 * max(1.0, meta["out_absmax"])
