@@ -27,7 +27,7 @@ class LayerWeights(C.Structure):
     _fields_ = [("ln1_g", fp), ("ln1_b", fp), ("ln2_g", fp), ("ln2_b", fp),
                 ("w_qkv", vp), ("b_qkv", fp), ("w_o", vp), ("b_o", fp),
                 ("w_1", vp), ("b_1", fp), ("w_2", vp), ("b_2", fp),
-                ("qkv_colsum", fp), ("w1_colsum", fp)]
+                ("qkv_colsum", fp), ("w1_colsum", fp), ("w_1f", vp), ("w_2f", vp)]
 
 
 class DenoiserWeights(C.Structure):
@@ -99,6 +99,7 @@ _SIGNATURES = {
     "bg_embed_ln_silu_fwd": (C.c_int, [fp, C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, vp, C.c_int, C.c_float, vp]),
     "bg_ln_silu_out_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "bg_ffn_fused_fwd": (C.c_int, [vp, vp, fp, vp, fp, fp, vp, fp, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp]),
     "bg_qkv_attn_fwd": (C.c_int, [vp, vp, fp, fp, fp, u8p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_qkv_attn_paired_fwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_compact_rows_paired": (C.c_int, [u8p, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -133,7 +134,7 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES)
 
-ABI_VERSION = 5          # BG_ABI_VERSION of include/brepgen_hip.h this binding was written against
+ABI_VERSION = 6          # BG_ABI_VERSION of include/brepgen_hip.h this binding was written against
 
 _lib = None
 

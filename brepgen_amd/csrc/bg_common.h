@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_OUT_TAIL, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_OUT_TAIL, PK_FFN_FUSED, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -35,8 +35,8 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
-//  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_COUNT = 16 };
+//  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold; 16: 1 = FFN1 and FFN2 as two launches even where w_1f / w_2f are given -- each backs a bit-equality test, see gemm_16bit.hip launch16)
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_COUNT = 17 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -302,6 +302,18 @@ int cond_vector_table(const float* table, int table_rows, const int64_t* timeste
 bool ln_silu_out_supported(int n_out, int n_out_pad);
 int ln_silu_out(const void* t0, const float* gam, const float* bet, const void* w3, const float* b3, float* out, int n_out, int n_out_pad,
                 int M, int dtype, float eps, hipStream_t s, const int* m_dev = nullptr, const int* row_map = nullptr, double rows_hint = 0.0);
+// FFN1 (LayerNorm fold, ReLU) + FFN2 (split residual in place + row statistics) of an encoder layer in one launch (ffn_fused.hip)
+struct FfnArgs {
+    void* xh; void* xl;                 // residual planes [M, 768], updated in place
+    float* stats;                       // [12][m_stride][2]: LayerNorm-2 partials in, the new rows' partials out
+    const void* w1f; const float* b1; const float* colsum1;     // W1' in fragment order, b1' = b1 + W1 beta, column sums of W1'
+    const void* w2f; const float* b2;
+    int M, m_stride;
+    const int* m_dev;
+    float ln_eps;
+};
+bool ffn_fused_eligible(const FfnArgs& g, int dtype);
+int ffn_fused(const FfnArgs& g, int dtype, hipStream_t s, double rows_hint);
 // out = f32 -> bf16 cast (n elements, n % 4 == 0)
 int cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
 

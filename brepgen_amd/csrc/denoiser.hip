@@ -37,7 +37,7 @@ bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(generic: 128x64 / 64x64 tiles)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
                                           "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
                                           "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)",
-                                          "qkv_attn_kernel(256x192 + attention)", "ln_silu_out_kernel"};
+                                          "qkv_attn_kernel(256x192 + attention)", "ln_silu_out_kernel", "ffn_fused_kernel(64-row panels)"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {
@@ -336,6 +336,13 @@ static int run(const bg_denoiser_weights* w, const bg_denoiser_inputs* in, float
         op.out_lo = c.XL; op.res_hi = c.XH; op.res_lo = c.XL; op.ld_res = 768; op.stats_out = c.stats;
         op.m_dev = c.m_dev; op.rule_table = c.rule; op.rows_hint = c.rows_hint; op.rows_plan = c.rows_plan; op.concurrent = c.concurrent;
         if ((rc = gemm(op, c.dtype, s))) return rc;
+        if (L.w_1f && L.w_2f && g_tune[TUNE_FFN_FUSED] != 1) {
+            // FFN1 + ReLU + FFN2 + residual as one launch: the [M, 1024] hidden tensor stays in the CU's LDS (ffn_fused.hip; bit-identical)
+            FfnArgs ff{c.XH, c.XL, c.stats, L.w_1f, L.b_1, L.w1_colsum, L.w_2f, L.b_2, M, M, c.m_dev, 1e-5f};      // (statistics stride = the launch's row bound, as the GEMMs')
+            BG_REQUIRE(ffn_fused_eligible(ff, c.dtype), BG_E_ARG, "bg_denoiser_fwd: w_1f / w_2f given, but the fused FFN launch does not apply");
+            if ((rc = ffn_fused(ff, c.dtype, s, c.rows_hint))) return rc;
+            continue;
+        }
         GemmArgs f1{c.XH, 768, L.w_1, L.b_1, c.R, 1024, M, 1024, 1024, 768, c.dtype, BG_ACT_RELU, nullptr, 0, 1};
         f1.stats_in = c.stats; f1.colsum = L.w1_colsum;
         f1.m_dev = c.m_dev; f1.rule_table = c.rule; f1.rows_hint = c.rows_hint; f1.rows_plan = c.rows_plan; f1.concurrent = c.concurrent;

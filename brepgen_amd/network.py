@@ -80,6 +80,15 @@ def mfma_operand_order(w0):
     return w0.reshape(24, 32, k // 2, 2).permute(0, 2, 3, 1).reshape(24, k // 2, 64).contiguous()
 
 
+def ffn_fragment_order(w, tiles):
+    """w [8 * tiles * 32, K] (16-bit) -> [8, K/16, tiles, 64, 8]: per wave (8), per 16-wide k-slice, per 32-row tile ONE contiguous
+    KiB holding, for lane l, the eight k values 16 s + 8 (l >> 5) ... of row (l & 31) of the tile -- the A operand of
+    v_mfma_f32_32x32x16 as it sits in registers, so csrc/ffn_fused.hip streams its weights as coalesced 16-byte loads with no LDS."""
+    n, k = w.shape
+    assert n == 8 * tiles * 32 and k % 16 == 0
+    return w.reshape(8, tiles, 32, k // 16, 2, 8).permute(0, 3, 1, 4, 2, 5).contiguous()
+
+
 class _HipDenoiser(nn.Module):
     NET = None            # bg_net id
     EMBEDS = ()           # embed-MLP attribute names in the order of bg_denoiser_weights.embed[]
@@ -102,6 +111,7 @@ class _HipDenoiser(nn.Module):
         # cancels two large terms when a checkpoint's rows have |mean| >> std, nor does the 16-bit hi plane spend its mantissa on the
         # offset (tests/golden/*_stress_offset_*: fold error 1.9 x the un-folded path without this, 1.0 x with it).
         self.center_stream = True
+        self.fuse_ffn = True             # 16-bit fold modes: FFN1 + ReLU + FFN2 + residual of a layer as one launch (csrc/ffn_fused.hip)
         # the time-embedding MLP evaluated once for t = 0 .. time_table_steps - 1 (num_train_timesteps of the reference's schedulers,
         # sample.py:101-117) and looked up per evaluation; 0 = recomputed per call.  A timestep outside the table gives NaN.
         self.time_table_steps = 1000
@@ -136,7 +146,8 @@ class _HipDenoiser(nn.Module):
     def _pack(self, dt):
         fold = bool(self.fold_layernorm) and dt != torch.float32
         center = fold and bool(self.center_stream)
-        key = (dt, fold, center, bool(self.fuse_embed), bool(self.fuse_output), int(self.time_table_steps or 0))   # of the packed descriptor
+        fuse_ffn = fold and bool(self.fuse_ffn)
+        key = (dt, fold, center, fuse_ffn, bool(self.fuse_embed), bool(self.fuse_output), int(self.time_table_steps or 0))   # of the packed descriptor
         if key in self._packs:
             return self._packs[key]
         keep = []                                        # owns every packed tensor the descriptor points to
@@ -216,6 +227,7 @@ class _HipDenoiser(nn.Module):
                 L.b_qkv = f32(bq + (wq * layer.norm1.bias.detach().to(torch.float32)[None, :]).sum(1))
                 w1 = layer.linear1.weight.detach().to(torch.float32)
                 L.w_1 = mat(layer.linear1.weight, gamma=layer.norm2.weight)
+                w1_packed = keep[-1]
                 L.w1_colsum = f32(keep[-1].to(torch.float32).sum(1))
                 L.b_1 = f32(layer.linear1.bias.detach().to(torch.float32) + (w1 * layer.norm2.bias.detach().to(torch.float32)[None, :]).sum(1))
             else:
@@ -224,7 +236,15 @@ class _HipDenoiser(nn.Module):
                 L.w_1, L.b_1 = mat(layer.linear1.weight), f32(layer.linear1.bias)
                 L.qkv_colsum = L.w1_colsum = None
             L.w_o, L.b_o = mat(layer.self_attn.out_proj.weight, centered=center), cvec(layer.self_attn.out_proj.bias)
-            L.w_2, L.b_2 = mat(layer.linear2.weight, centered=center), cvec(layer.linear2.bias)
+            L.w_2 = mat(layer.linear2.weight, centered=center)
+            w2_packed = keep[-1]
+            L.b_2 = cvec(layer.linear2.bias)
+            L.w_1f = L.w_2f = None
+            if fuse_ffn:
+                keep.append(ffn_fragment_order(w1_packed, 4))
+                L.w_1f = keep[-1].data_ptr()
+                keep.append(ffn_fragment_order(w2_packed, 3))
+                L.w_2f = keep[-1].data_ptr()
         w.lnf_g, w.lnf_b = f32(self.net.norm.weight), f32(self.net.norm.bias)
         w.time_embed = mlp(self.time_embed, writes_stream=True)
         w.fc_out = mlp(self.fc_out, w0_compute=True, fold_norm=self.net.norm if (fold and self.fuse_output) else None)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 5
+#define BG_ABI_VERSION 6
 
 typedef void* bg_stream_t;              /* hipStream_t */
 
@@ -145,6 +145,15 @@ int bg_attn_varlen_fwd(const void* qkv, const uint8_t* key_pad, void* out, int B
  * that GEMM. */
 int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, const float* colsum, const float* stats_in,
                     const uint8_t* key_pad, void* out, void* qkv_dbg, int B, int N, int dtype, float ln_eps, bg_stream_t stream);
+/* FFN1 (LayerNorm fold, ReLU) + FFN2 (split residual in place + row statistics) of one encoder layer in ONE launch
+ * (csrc/ffn_fused.hip; network.py:1076-1078, dim_feedforward = 1024): the residual planes x_hi / x_lo [M, 768] (16-bit, dtype) are
+ * updated in place, stats [12][m_stride][2] holds the row-statistics partials of x on entry and those of the new x on return;
+ * w1_frag / w2_frag: bg_layer_weights.w_1f / w_2f; b1 / colsum1: the fold's bias and column sums [1024]; b2 [768].  m_dev (may be
+ * NULL): device-side row count <= M.  Bit for bit what bg_gemm_ex_fwd (fold, ReLU) followed by bg_gemm_ex_fwd (split residual +
+ * statistics) produce. */
+int bg_ffn_fused_fwd(void* x_hi, void* x_lo, float* stats, const void* w1_frag, const float* b1, const float* colsum1,
+                     const void* w2_frag, const float* b2, int M, int m_stride, const int* m_dev, int dtype, float ln_eps,
+                     bg_stream_t stream);
 /* The same launch on a SLOT-PACKED ragged batch (bg_compact_rows_paired): *m_dev rows (device-side, a multiple of 64) in 64-row
  * slots of one or two whole samples, slot_desc[2 k] / [2 k + 1] their lengths, at most slot_bound slots; m_stats = row stride of
  * stats_in.  out rows = what bg_gemm_ex_fwd + bg_attn_varlen_fwd produce for the same samples on the dense packing, bit for bit.
@@ -207,6 +216,12 @@ typedef struct {            /* one nn.TransformerEncoderLayer (norm_first) */
      * residual rows and applies mean / rstd per row in its epilogue. */
     const float* qkv_colsum; /* fp32 [2304] */
     const float* w1_colsum;  /* fp32 [1024] */
+    /* optional (ABI 6; both NULL = FFN1 and FFN2 stay two launches): the SAME folded w_1 / w_2 once more, in MFMA fragment order for
+     * bg_ffn_fused_fwd (one launch per layer for FFN1 + ReLU + FFN2 + residual, the hidden tensor never leaves the CU):
+     *   w_1f[w][s][j][lane][e] = w_1[(4 w + j) * 32 + (lane & 31)][16 s + 8 (lane >> 5) + e]   w < 8, s < 48, j < 4, lane < 64, e < 8
+     *   w_2f[w][s][j][lane][e] = w_2[(3 w + j) * 32 + (lane & 31)][16 s + 8 (lane >> 5) + e]   w < 8, s < 64, j < 3 */
+    const void* w_1f;
+    const void* w_2f;
 } bg_layer_weights;
 
 typedef struct {

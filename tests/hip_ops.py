@@ -198,3 +198,19 @@ def ln_silu_out(t0, gamma, beta, w3, b3, n_out, eps=1e-5):
                                          ptr(out), n_out, w3.shape[0], t0.shape[0], bg_dtype(t0.dtype), eps, stream()),
           "bg_ln_silu_out_fwd")
     return out
+
+
+def ffn_fused(hi, lo, stats, w1, b1, colsum1, w2, b2, m_dev=None, ln_eps=1e-5):
+    """bg_ffn_fused_fwd: FFN1 (LayerNorm fold, ReLU) + FFN2 (split residual + statistics) in one launch, IN PLACE on clones of
+    (hi, lo, stats).  w1 [1024, 768] / w2 [768, 1024]: the folded 16-bit matrices in their row-major form (fragment order is made
+    here, by the product's own packer).  Returns (hi, lo, stats)."""
+    from brepgen_amd.network import ffn_fragment_order
+    _need_cuda(hi, lo, stats, w1, b1, colsum1, w2, b2)
+    hi, lo, stats = hi.clone(), lo.clone(), stats.clone()
+    M = hi.shape[0]
+    assert hi.shape == (M, 768) and lo.shape == hi.shape and stats.shape[0] == 12 and stats.shape[2] == 2
+    w1f, w2f = ffn_fragment_order(w1.contiguous(), 4), ffn_fragment_order(w2.contiguous(), 3)
+    check(_lib.load().bg_ffn_fused_fwd(ptr(hi), ptr(lo), ptr(stats), ptr(w1f), ptr(b1.contiguous()), ptr(colsum1.contiguous()), ptr(w2f),
+                                       ptr(b2.contiguous()), M, stats.shape[1], ptr(m_dev), bg_dtype(hi.dtype), ln_eps, stream()),
+          "bg_ffn_fused_fwd")
+    return hi, lo, stats
