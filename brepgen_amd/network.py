@@ -111,7 +111,9 @@ class _HipDenoiser(nn.Module):
         # cancels two large terms when a checkpoint's rows have |mean| >> std, nor does the 16-bit hi plane spend its mantissa on the
         # offset (tests/golden/*_stress_offset_*: fold error 1.9 x the un-folded path without this, 1.0 x with it).
         self.center_stream = True
-        self.fuse_ffn = True             # 16-bit fold modes: FFN1 + ReLU + FFN2 + residual of a layer as one launch (csrc/ffn_fused.hip)
+        # 16-bit fold modes: FFN1 + ReLU + FFN2 + residual of a layer as ONE launch (csrc/ffn_fused.hip; bit-identical).  Off by default:
+        # measured 0.88-0.97 x the two launches it replaces (a 64-row panel pulls 3 MB of weights through its CU).
+        self.fuse_ffn = False
         # the time-embedding MLP evaluated once for t = 0 .. time_table_steps - 1 (num_train_timesteps of the reference's schedulers,
         # sample.py:101-117) and looked up per evaluation; 0 = recomputed per call.  A timestep outside the table gives NaN.
         self.time_table_steps = 1000

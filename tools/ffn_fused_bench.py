@@ -66,5 +66,33 @@ def main():
                       f"two launches {tt:7.1f} us = {fl / tt / 1e6:6.0f} TF", flush=True)
 
 
+def stamps(M=30720):
+    """s_memtime of workgroup 0 at the phase boundaries of its panels (100 MHz ticks -> us)."""
+    lib = _lib.load()
+    hi, lo, stats, w1, b1, colsum1, w2, b2 = _ffn_operands(M, torch.bfloat16, 1)
+    w1f, w2f = ffn_fragment_order(w1, 4), ffn_fragment_order(w2, 3)
+    buf = torch.zeros(32, dtype=torch.int64, device="cuda")
+    addr = buf.data_ptr()
+    run = lambda: check(lib.bg_ffn_fused_fwd(ptr(hi), ptr(lo), ptr(stats), ptr(w1f), ptr(b1), ptr(colsum1), ptr(w2f), ptr(b2), M, M, None,
+                                             ops.bg_dtype(torch.bfloat16), 1e-5, stream()), "ffn")
+    for _ in range(3):
+        run()
+    lib.bg_tune_set(17, addr & 0xffffffff if (addr & 0xffffffff) < 2 ** 31 else (addr & 0xffffffff) - 2 ** 32)
+    lib.bg_tune_set(18, addr >> 32)
+    run()
+    torch.cuda.synchronize()
+    lib.bg_tune_set(17, 0)
+    lib.bg_tune_set(18, 0)
+    t = buf.tolist()
+    names = ["x panel -> LDS + barrier", "phase 1", "barrier wait", "epilogue 1 + barrier", "phase 2", "epilogue 2", "barrier wait + merge", "(loop)"]
+    n = 8
+    for k in range(0, 16, n):
+        seg = t[k:k + n + 1]
+        print("panel", k // n, "cycles:", " | ".join(f"{names[i]} {seg[i + 1] - seg[i]}" for i in range(n) if seg[i + 1] and seg[i]), "| total", seg[n - 1] - seg[0])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+        stamps()
+        sys.exit(0)
     main()
