@@ -173,15 +173,9 @@ def cpu_baseline(steps=2, warmup=1):
             "calibration_s_per_sample_step": {str(k): round(v, 3) for k, v in calib.items()}}
 
 
-def sustained_clock_extra(dev, secs=0.6):
-    """Reported BESIDE the headline: what the part sustains under the MFMA-bound launch of the step (the fused QKV + attention
-    launch of SurfPosNet at 512 x 60) -- microseconds per launch, package power and shader clock (hwmon of THIS device), with the
-    bench's random operands and with all-zero operands (the same instruction stream, no bits toggling).  The roofline's MFMA peak
-    assumes 2.4 GHz; with random 16-bit operands the 1400 W cap leaves less (DESIGN.md section 4)."""
+def _sensors(dev):
+    """hwmon files of THIS device: package power (W), shader clock (MHz), power cap (W) -> read(key) in the sensor's unit / 1e6."""
     import glob
-    import threading
-    from brepgen_amd import _lib
-    lib = _lib.load()
     pr = torch.cuda.get_device_properties(dev)
     want = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") else None
     sens = {}
@@ -199,6 +193,48 @@ def sustained_clock_extra(dev, secs=0.6):
             return int(open(sens[key]).read()) / 1e6
         except (KeyError, OSError, ValueError):
             return None
+    return read
+
+
+def face_ldm_full_pass_extra(ldm, dev, barrier):
+    """ONE real face LDM as sample.py:126-202 runs it -- 158 + 250 + 209 iterations back to back (the headline's timed region is
+    a short, step-weighted sample of it) -- with the package power and shader clock sampled while it runs: what the part SUSTAINS
+    over ~2 s of this step mix, not over 60 ms."""
+    import threading
+    read = _sensors(dev)
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            samples.append((read("W"), read("MHz")))
+            time.sleep(0.02)
+    ldm.run(1, 1, 1)
+    barrier()
+    th = threading.Thread(target=poll)
+    th.start()
+    t0 = time.perf_counter()
+    ldm.run(158, 250, 209)
+    barrier()
+    d = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    tail = samples[len(samples) // 2:]
+    med = lambda v: (sorted(v)[len(v) // 2] if v else None)
+    return {"iterations": {"A": 158, "B": 250, "C": 209}, "seconds": round(d, 4), "ms_per_step": round(1e3 * d / 617, 4),
+            "steps_per_s_per_gpu": round(617 / d, 2), "samples_per_s_per_gpu": round(B_PER_GPU / d, 1),
+            "power_W_second_half": med([p for p, _ in tail if p is not None]),
+            "shader_clock_MHz_second_half": med([f for _, f in tail if f is not None])}
+
+
+def sustained_clock_extra(dev, secs=0.6):
+    """Reported BESIDE the headline: what the part sustains under the MFMA-bound launch of the step (the fused QKV + attention
+    launch of SurfPosNet at 512 x 60) -- microseconds per launch, package power and shader clock (hwmon of THIS device), with the
+    bench's random operands and with all-zero operands (the same instruction stream, no bits toggling).  The roofline's MFMA peak
+    assumes 2.4 GHz; with random 16-bit operands the 1400 W cap leaves less (DESIGN.md section 4)."""
+    import threading
+    from brepgen_amd import _lib
+    lib = _lib.load()
+    read = _sensors(dev)
 
     B, N = B_PER_GPU, N_FACE
     M = B * N
@@ -417,12 +453,95 @@ def cascade_extra():
     return cascade_bench.run(256)
 
 
-def rank_local_extra(name, k=3):
-    """BASELINE configs[3] / configs[4] as one rank runs them (tools/rank_local_bench.py): K iterations of each of the four
-    cascade loops at the rank-local batch, per-iteration times and the projected full loops."""
+def rank_local_extra(name, k=None):
+    """BASELINE configs[3] / configs[4] as one rank runs them (tools/rank_local_bench.py): the four cascade loops IN FULL
+    (408 + 209 + 408 + 209 iterations) at the rank-local batch, measured in this run (~90 s + ~75 s)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import rank_local_bench
     return rank_local_bench.run(name, k)
+
+
+def torch_eager_extra(dev, steps=10, warmup=3):
+    """The like-for-like "reference PyTorch on this GPU" figure: the reference's formulation of
+    SurfZNet (oracle/ref_formulation.py: stock nn.TransformerEncoder seq-first, as network.py:1133-1200 composes it) through
+    torch-ROCm EAGER on this device -- fp32 and under torch.autocast (fp16: what sample.py:121 runs; bf16: the bench's dtype) --
+    one eps-evaluation at the headline's loop-C shape (512 x 60, key-padding mask) + the scheduler update in torch ops."""
+    from oracle import denoisers as orc
+    from oracle import ref_formulation as rf
+    net = rf.build("SurfZNet", orc.seeded_state_dict("SurfZNet", 0)).to(dev).eval()
+    z, pos, mask = (t.to(dev) for t in make_inputs(B_PER_GPU, "cpu", 1234))
+    t = torch.tensor([249], device=dev)
+    out = {"workload": "SurfZNet eps-evaluation, 512 x 60 tokens + key-padding mask, dense (as the reference runs it), torch-ROCm eager",
+           "torch": torch.__version__}
+    for name, dt in (("autocast_bf16", torch.bfloat16), ("autocast_fp16", torch.float16), ("fp32", None)):
+        def fn():
+            with torch.no_grad():
+                if dt is None:
+                    return net(z, t, pos, mask, None)
+                with torch.autocast("cuda", dtype=dt):
+                    return net(z, t, pos, mask, None)
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eps = fn()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[name] = {"ms_per_eval": round(ms, 3), "evals_per_s": round(1e3 / ms, 2), "finite": bool(torch.isfinite(eps[~mask]).all())}
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_stage_baselines(threads):
+    """CPU cost of the stages of BASELINE configs[2] / [3] / [4]: the reference's formulation
+    (oracle/ref_formulation.py, fp32, dense -- every padded position, as the reference computes it) of each eps-net at a REDUCED
+    batch, ONE timed evaluation after one warm-up, scaled linearly in the batch (every op of the path is per-sample) and
+    multiplied by the loop's iteration count (sample.py:128-282; x 2 evaluations per iteration with classifier-free guidance).
+    A projection, stated as such: the only measured quantities are `s_per_eval` at `batch_timed`."""
+    from oracle import denoisers as orc
+    from oracle import ref_formulation as rf
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(11)
+    R = lambda *sh: torch.randn(*sh, generator=g)
+    t = torch.tensor([249])
+
+    def clock(fn):
+        with torch.no_grad():
+            fn()
+            t0 = time.perf_counter()
+            fn()
+        return time.perf_counter() - t0
+
+    nets = {n: rf.build(n, orc.seeded_state_dict(n, 0)) for n in ("SurfPosNet", "SurfZNet", "EdgePosNet", "EdgeZNet")}
+
+    def stage_times(S, E, b_face, b_edge, s_first):
+        m_face = torch.zeros(b_face, S, dtype=torch.bool)
+        m_edge = torch.zeros(b_edge, S, dtype=torch.bool)
+        em = torch.zeros(b_edge, S, E, dtype=torch.bool)
+        return {
+            "surfPos_first158": clock(lambda: nets["SurfPosNet"](R(b_face, s_first, 6), t, None)) / b_face,
+            "surfPos": clock(lambda: nets["SurfPosNet"](R(b_face, S, 6), t, None)) / b_face,
+            "surfZ": clock(lambda: nets["SurfZNet"](R(b_face, S, 48), t, R(b_face, S, 6), m_face, None)) / b_face,
+            "edgePos": clock(lambda: nets["EdgePosNet"](R(b_edge, S, E, 6), t, R(b_edge, S, 6), R(b_edge, S, 48), m_edge, None)) / b_edge,
+            "edgeZV": clock(lambda: nets["EdgeZNet"](R(b_edge, S, E, 18), t, R(b_edge, S, E, 6), R(b_edge, S, 6), R(b_edge, S, 48), em, None)) / b_edge,
+        }
+
+    out = {"threads": threads, "formulation": "oracle/ref_formulation.py (stock nn.TransformerEncoder, seq-first), fp32, dense, torch CPU",
+           "projection": "loop seconds = s_per_eval_per_sample x batch x iterations (x 2 evaluations with guidance); without guidance the "
+                         "first 158 surfPos iterations run on half the faces (the late doubling, sample.py:139-142)"}
+    for name, S, E, B, evals, what in (("cfg3", 60, 30, 256, 1, "DeepCAD cascade, batch 256 (2 x 30 faces x 30 edges = 1800 edge tokens)"),
+                                       ("cfg4", 100, 40, 512, 1, "ABC, one rank's 512 samples (2 x 50 faces x 40 edges = 4000 edge tokens)"),
+                                       ("cfg5", 60, 40, 256, 2, "furniture, one rank's 256 samples, classifier-free guidance (60 faces x 40 edges = 2400 edge tokens)")):
+        st = stage_times(S, E, 4, 1, S // 2 if evals == 1 else S)
+        loops = {"surfPos": B * evals * (158 * st["surfPos_first158"] + 250 * st["surfPos"]), "surfZ": B * evals * 209 * st["surfZ"],
+                 "edgePos": B * evals * 408 * st["edgePos"], "edgeZV": B * evals * 209 * st["edgeZV"]}
+        out[name] = {"workload": what, "batch_timed": {"face_nets": 4, "edge_nets": 1},
+                     "s_per_eval_per_sample": {k: round(v, 4) for k, v in st.items()},
+                     "projected_loop_s": {k: round(v, 1) for k, v in loops.items()}, "projected_loops_s": round(sum(loops.values()), 1),
+                     "projected_samples_per_s": round(B / sum(loops.values()), 5)}
+    return out
 
 
 def pmc_traffic(kernel, launches_per_step):
@@ -655,8 +774,16 @@ def main():
                                                   "ms_per_step": round(ms / args.steps, 4)}
 
     if world == 1 and rank == 0 and not args.no_extra:
+        try:
+            extra["face_ldm_full_pass"] = face_ldm_full_pass_extra(ldm, dev, barrier)
+        except Exception as e:
+            extra["face_ldm_full_pass"] = {"error": repr(e)}
         ldm = None
         torch.cuda.empty_cache()
+        try:
+            extra["torch_eager_reference_formulation"] = torch_eager_extra(dev)
+        except Exception as e:
+            extra["torch_eager_reference_formulation"] = {"error": repr(e)}
         extra["edge_nets"] = edge_net_extra(dev)
         try:
             extra["sustained_clock"] = sustained_clock_extra(dev)
@@ -706,6 +833,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            if not args.no_extra:
+                # (GPU side of the same configurations: extra.cascade_cfg3 / rank_local_cfg4 / rank_local_cfg5, measured above)
+                try:
+                    st = cpu_stage_baselines(line["cpu_baseline"]["threads"])
+                    for name, gpu_key in (("cfg3", "cascade_cfg3"), ("cfg4", "rank_local_cfg4"), ("cfg5", "rank_local_cfg5")):
+                        gpu = extra.get(gpu_key, {})
+                        gpu_s = gpu.get("cascade_s") or gpu.get("loops_s")
+                        if gpu_s and name in st:
+                            st[name]["gpu_loops_s_this_run"] = gpu_s
+                            st[name]["gpu_over_cpu_projection"] = round(st[name]["projected_loops_s"] / gpu_s, 1)
+                    line["cpu_baseline"]["cascade_stages"] = st
+                except Exception as e:
+                    line["cpu_baseline"]["cascade_stages"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -61,18 +61,7 @@ def run(name, k=None):
         # times below are therefore an UPPER bound on the full loops' -- they are the cost at the token counts printed beside them;
         # the full loops, run once per round, are in profiles/ (full_run).
         out["note"] = ("K-iteration run: per-iteration times at the validity such a short run leaves (valid_* above), an upper bound "
-                       "on the full loops' per-iteration times; full loops measured once per round: full_run")
-        try:
-            import glob
-            path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"rank_local_{name}_full.json")))[-1]
-            with open(path) as f:
-                full = json.load(f)
-            out["full_run"] = {"source": os.path.relpath(path, ROOT) + " (stored measurement, not taken in this run)",
-                               "loops_s": full["loops_s"], "stage_s": full["stage_s"], "ms_per_iteration": full["ms_per_iteration"],
-                               "samples_per_s_per_rank": full.get("samples_per_s_per_rank"),
-                               "valid_faces_mean": full["valid_faces_mean"], "valid_edges_mean_per_sample": full["valid_edges_mean_per_sample"]}
-        except (IndexError, OSError, ValueError, KeyError):
-            out["full_run"] = None
+                       "on the full loops' per-iteration times")
     else:
         out["samples_per_s_per_rank"] = round(B / total, 2)
     del nets, sampler, lat
