@@ -126,6 +126,8 @@ _SIGNATURES = {
     "bg_profile_begin": (C.c_int, [C.c_int]),
     "bg_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int]),
     "bg_tune_set": (C.c_int, [C.c_int, C.c_int]),
+    "bg_allgather": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "bg_slot_packing_applies": (C.c_int, [C.c_int] * 6),
     "bg_gemm_p256_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "bg_add_noise": (C.c_int, [fp, fp, fp, fp, fp, C.c_int, C.c_size_t, vp]),
     "bg_chamfer_offset_fit": (C.c_int, [fp, fp, vp, C.c_int, C.c_int, C.c_int] + [C.c_double] * 5 + [fp, fp, fp, vp]),

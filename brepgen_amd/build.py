@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbrepgen_hip.so")
-SOURCES = ["elementwise.hip", "embed.hip", "gemm_f32.hip", "gemm_16bit.hip", "gemm_p256.hip", "gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip", "out_tail.hip", "attn.hip", "vae.hip", "dedup.hip", "chamfer.hip", "rng.hip", "compact.hip", "vae_exec.hip", "denoiser.hip"]
+SOURCES = ["elementwise.hip", "embed.hip", "gemm_f32.hip", "gemm_16bit.hip", "gemm_p256.hip", "gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip", "out_tail.hip", "attn.hip", "vae.hip", "dedup.hip", "chamfer.hip", "rng.hip", "compact.hip", "vae_exec.hip", "collective.hip", "denoiser.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -23,6 +23,18 @@ def _hipcc():
     if not os.path.exists(exe):
         raise RuntimeError("hipcc not found: libbrepgen_hip.so cannot be built")
     return exe
+
+
+def _source_digest():
+    """Digest of the kernel sources + flags alone (no compiler version): what a box WITHOUT hipcc can still re-derive, to notice a
+    prebuilt library that is older than the csrc next to it."""
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + ["../../include/brepgen_hip.h"]
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
 
 
 def _digest():
@@ -60,6 +72,11 @@ def build(force=False, save_temps=False, verbose=True):
         # a box without a compiler: the prebuilt library that travelled with the tree is what there is (its digest cannot be
         # re-derived without hipcc's version string); without it there is nothing to load -- fail loudly
         if os.path.exists(LIB) and not force:
+            src_stamp = os.path.join(OBJ, "digest_sources.txt")
+            if os.path.exists(src_stamp) and open(src_stamp).read() != _source_digest():
+                # same ABI number, different kernels: running them silently would be a stale build; there is no compiler to fix it here
+                raise RuntimeError("libbrepgen_hip.so was built from other sources than brepgen_amd/csrc now holds (digest_sources.txt "
+                                   "differs) and there is no hipcc on this box to rebuild it: build on a box with ROCm first")
             return LIB
         _hipcc()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
@@ -71,12 +88,14 @@ def build(force=False, save_temps=False, verbose=True):
         if verbose and warn.strip():
             sys.stderr.write(warn)
     objs = [o for o, _ in results]
-    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB],
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     with open(stamp, "w") as f:
         f.write(dig)
+    with open(os.path.join(OBJ, "digest_sources.txt"), "w") as f:
+        f.write(_source_digest())
     return LIB
 
 

@@ -251,6 +251,9 @@ __global__ __launch_bounds__(64) void fill_clones_kernel(const int* __restrict__
 // (rep == 1, n_mask <= 64.)  offsets [B + 1], src_row [64 B], slot_desc [2 B], slot_a [B]
 int compact_rows_paired(const uint8_t* mask, int B, int n_mask, int* offsets, int* src_row, int* slot_desc, int* slot_a,
                         int* counts, hipStream_t s, int* rule) {
+    // (pair_slots_kernel keeps sample indices in 16 bits and lengths in 8, and its dynamic LDS grows with B: guarded HERE, not only
+    //  at the extern "C" entry, because the denoiser calls this function directly)
+    BG_REQUIRE(B > 0 && B <= 8192 && n_mask > 0 && n_mask <= 64, BG_E_SHAPE, "compact_rows_paired: 1 .. 8192 samples of 1 .. 64 tokens");
     ProfScope prof(PK_MISC, 0.0, (double)B * n_mask * 6.0, s);
     hipLaunchKernelGGL(count_valid_kernel, dim3(B), dim3(256), 0, s, mask, n_mask, 1, counts);
     hipLaunchKernelGGL(pair_slots_kernel, dim3(1), dim3(1024), pair_slots_lds_bytes(B), s, counts, B, offsets, slot_desc, slot_a, rule);

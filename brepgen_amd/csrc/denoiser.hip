@@ -497,6 +497,12 @@ static SplitState* split_state() {
 }
 }  // namespace bg
 
+extern "C" int bg_slot_packing_applies(int net, int B, int S, int E, int dtype, int fold) {
+    // the predicate bg_denoiser_fwd itself evaluates for a variable-length call (`paired`), for hosts that want to compute rows_plan
+    if (net < BG_EDGEPOS) E = 1;
+    return (bg::slot_packing_applies(net, B, S, E, dtype) && fold != 0 && bg::g_tune[bg::TUNE_QKV_ATTN] != 1) ? 1 : 0;
+}
+
 extern "C" size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype) {
     if (B <= 0 || S <= 0) return 0;
     if (net < BG_EDGEPOS) E = 1;

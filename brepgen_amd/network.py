@@ -114,8 +114,10 @@ class _HipDenoiser(nn.Module):
         # 16-bit fold modes: FFN1 + ReLU + FFN2 + residual of a layer as ONE launch (csrc/ffn_fused.hip; bit-identical).  Off by default:
         # measured 0.88-0.97 x the two launches it replaces (a 64-row panel pulls 3 MB of weights through its CU).
         self.fuse_ffn = False
-        # the time-embedding MLP evaluated once for t = 0 .. time_table_steps - 1 (num_train_timesteps of the reference's schedulers,
-        # sample.py:101-117) and looked up per evaluation; 0 = recomputed per call.  A timestep outside the table gives NaN.
+        # the time-embedding MLP evaluated once for t = 0 .. time_table_steps - 1 and looked up per evaluation; 0 = recomputed per call
+        # (any t, like the reference).  A timestep OUTSIDE the table gives NaN rows -- loud, not silent.  1000 = num_train_timesteps of the
+        # reference's schedulers (sample.py:101-117); CascadeSampler / training.py raise it to their schedulers' num_train_timesteps, a
+        # caller with another timestep convention sets it (or 0) itself.
         self.time_table_steps = 1000
         # Variable-length execution (nets that take a mask): only the VALID tokens run through the network (compacted on
         # the device, no host sync); eps at padded positions is 0 where the reference returns values nobody reads
@@ -331,7 +333,8 @@ class _HipDenoiser(nn.Module):
     def _row_hints(self, mask, S, E, B, ns, paired):
         """((valid tokens, sum over samples of valid^2), rows_plan) of this mask -- the host-side numbers bg_denoiser_fwd takes: the
         ESTIMATE pair (GEMM kernel choice + profiler accounting) and, per sample group of the n_split, the EXACT row count the
-        kernels will see (valid tokens, or 64 x slots where the batch runs slot-packed: `paired`), which lets the launcher skip
+        kernels will see (valid tokens, or 64 x slots where the group runs slot-packed: `paired(group batch)`, the library's own
+        predicate), which lets the launcher skip
         launches that would find nothing to do.  The kernels always count the rows themselves.  Never a host synchronisation: a mask
         seen for the first time is only remembered; the second call with the same tensor starts an asynchronous count (a few tiny
         kernels + a copy into pinned memory behind an event) and still passes 0 = unknown; later calls use the count once the event
@@ -364,11 +367,11 @@ class _HipDenoiser(nn.Module):
             c = hc["host"].tolist()
             hc["counts"] = c
             hc["hints"] = (float(sum(c)), float(sum(v * v for v in c)))
-        pk = (int(ns), bool(paired))
+        groups = tuple(self._group_ranges(B, ns))
+        pk = (int(ns), tuple(paired(hi - lo) for lo, hi in groups))
         if pk not in hc["plans"]:
             c = hc["counts"]
-            hc["plans"][pk] = tuple(float(self._slot_rows(c[lo:hi]) if (paired and hi - lo <= 8192) else sum(c[lo:hi]))
-                                    for lo, hi in self._group_ranges(B, ns))
+            hc["plans"][pk] = tuple(float(self._slot_rows(c[lo:hi]) if pr else sum(c[lo:hi])) for (lo, hi), pr in zip(groups, pk[1]))
         return (self.profile_hints or hc["hints"]), hc["plans"][pk]
 
     def _run(self, x, timesteps, surf_pos, surf_z, edge_pos, mask, class_label, B, S, E, out_shape):
@@ -401,8 +404,10 @@ class _HipDenoiser(nn.Module):
         inp.n_split = int(ns)
         (inp.rows_hint, inp.pairs_hint), plan = (0.0, 0.0), ()
         if inp.varlen:
-            # (slot-packed execution: csrc/denoiser.hip slot_packing_applies + the LayerNorm-fold layers)
-            paired = self.NET == BG_SURFZ and dt != torch.float32 and bool(self.fold_layernorm) and S <= 64
+            # (slot-packed execution: the library's own predicate, csrc/denoiser.hip slot_packing_applies + the LayerNorm-fold layers + bg_tune)
+            # (evaluated per sample group: bg_denoiser_fwd runs every group as its own call)
+            fold_on = int(dt != torch.float32 and bool(self.fold_layernorm))
+            paired = lambda group_b: bool(_lib.load().bg_slot_packing_applies(self.NET, group_b, S, E, w.dtype, fold_on))
             (inp.rows_hint, inp.pairs_hint), plan = self._row_hints(mask, S, E, B, ns, paired)
         for k in range(4):
             inp.rows_plan[k] = plan[k] if k < len(plan) else 0.0

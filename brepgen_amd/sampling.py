@@ -220,6 +220,11 @@ class CascadeSampler:
         self.graphs = graphs
         self.nets = (surfpos, surfz, edgepos, edgez)
         self.pndm, self.ddpm = pndm, ddpm
+        # the nets' precomputed time-embedding tables must cover every timestep these schedulers can hand out
+        t_max = max(int(sch.config.num_train_timesteps) for sch in (pndm, ddpm))
+        for net in self.nets:
+            if net is not None and getattr(net, "time_table_steps", 0) and net.time_table_steps < t_max:
+                net.time_table_steps = t_max
         self.use_cf, self.class_id, self.w = use_cf, class_id, guidance
         self.thr = bbox_threshold
         self.dist = dist

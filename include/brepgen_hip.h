@@ -287,6 +287,12 @@ typedef struct {
     double rows_plan[4];
 } bg_denoiser_inputs;
 
+/* 1 when a variable-length call of bg_denoiser_fwd with these shapes runs SLOT-PACKED (64-row slots of one or two samples, the fused QKV +
+ * attention launch): the library's own predicate (net, shapes, 16-bit dtype, LayerNorm-fold weights given = `fold`, bg_tune key 13),
+ * exported so that a host that fills bg_denoiser_inputs.rows_plan counts the rows of the layout the library will actually use.
+ * rows_plan only ever chooses between launch plans that are all correct for any row count: it must never be used to skip work. */
+int bg_slot_packing_applies(int net, int B, int S, int E, int dtype, int fold);
+
 /* bytes of scratch bg_denoiser_fwd needs for these shapes (sized so that any n_split <= 4 fits) */
 size_t bg_workspace_bytes(int net, int B, int S, int E, int dtype);
 
@@ -439,6 +445,14 @@ typedef struct {
 int bg_profile_begin(int max_launches);
 int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number of rows written (<0: error) */
 
+/* ---- the path's one collective (batch sharding + ONE all-gather of the finished latents) ----
+ * recv[r * bytes_per_rank ...] = rank r's `send` (bytes_per_rank bytes each; device pointers; every rank passes the same size -- the
+ * Python host pads the last shard, brepgen_amd/sampling.py: gather_latents), enqueued on `stream`: a thin ncclAllGather (RCCL over
+ * xGMI) on a communicator the CALLER created with ncclCommInitRank (`nccl_comm` = the ncclComm_t).  For hosts without
+ * torch.distributed; the Python host uses all_gather_into_tensor on the "nccl" (= RCCL) backend, which is the same collective.
+ * RCCL is dlopen'ed at the first call; returns 0, BG_E_ARG, or 1000 + ncclResult_t. */
+int bg_allgather(const void* send, void* recv, size_t bytes_per_rank, void* nccl_comm, bg_stream_t stream);
+
 /* Kernel-selection knobs.  Every choice computes bit-identical results: the keys exist so that the parity tests can run the same
  * GEMM on each kernel that may serve it (0 always = the library's own choice; process-global, not for production use).
  *   key  8  split-residual launches on the 256 x 256 kernel: start delay of the second phase group, x 1024 cycles (< 0: none)
@@ -448,7 +462,10 @@ int bg_profile_end(bg_profile_row* rows, int max_rows);   /* returns the number 
  *           2 = fused wherever eligible (the library's own choice leaves a nearly empty second round of tiles to the two launches)
  *   key 14  tile walk of that fused kernel: 1 = plain (every XCD runs all 12 heads), 2 = XCD-pinned head halves wherever the grid
  *           allows (the library's own choice: from two rounds of tiles on)
- *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off) */
+ *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off)
+ *   key 16  FFN1 / FFN2 of layers that carry w_1f / w_2f: 1 = as two GEMM launches instead of the fused launch (bg_ffn_fused_fwd)
+ *   keys 17 / 18  measurement aid: low / high 32 bits of a device address that receives s_memtime stamps of the fused FFN launch's
+ *           phases (tools/ffn_fused_bench.py stamps); 0 / 0 = off */
 int bg_tune_set(int key, int value);
 
 /* How a 16-bit GEMM launch of `rows` x `n_cols` (n_cols a multiple of 256) is partitioned between the 256 x 256

@@ -200,13 +200,30 @@ def test_p256_kernels_do_not_spill():
             continue
         split = "ELi3E" in n                                     # MODE = P_SPLIT in the mangled name
         assert sc <= (8 if split else 0), (n, sc)
+    # ... and the one dword the split-residual kernels may spill must not be a destination of their inline-asm residual loads (those
+    # are invisible to hipcc's wait insertion: a spilled or reloaded destination would be read before the counted wait covers it).
+    # In the -S output the asm loads sit between ;;#ASMSTART / ;;#ASMEND markers; every scratch access names its register.
+    s_out = subprocess.run([b._hipcc(), *b.FLAGS, "-S", "--cuda-device-only", "-c", src, "-o", "-"], capture_output=True, text=True)
+    assert s_out.returncode == 0, s_out.stderr[-2000:]
+    for fn in re.split(r"\n(?=_ZN2bg18gemm16_p256_kernel)", s_out.stdout):
+        if not fn.startswith("_ZN2bg18gemm16_p256_kernel"):
+            continue
+        asm_dst = set()
+        for blk in re.findall(r";;#ASMSTART(.*?);;#ASMEND", fn, flags=re.S):
+            for lo, hi in re.findall(r"global_load_dwordx4 v\[(\d+):(\d+)\]", blk):
+                asm_dst.update(range(int(lo), int(hi) + 1))
+        scr = set()
+        for lo, hi in re.findall(r"scratch_(?:store|load)_dword\w* (?:off, )?v\[?(\d+)(?::(\d+))?", fn):
+            scr.update(range(int(lo), int(hi or lo) + 1))
+        assert not (asm_dst & scr), (fn[:60], sorted(asm_dst & scr))
 
 
-@pytest.mark.parametrize("src", ["gemm_split.hip", "qkv_attn.hip"])
+@pytest.mark.parametrize("src", ["gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip"])
 def test_hand_scheduled_kernels_do_not_spill(src):
     """csrc/gemm_split.hip runs at the 256-VGPR limit of two waves per SIMD (two accumulator sets + the slab in flight),
     csrc/qkv_attn.hip keeps 96 accumulators + 80 fragment registers + the fold temporaries live in its K loop; a spill would put
-    scratch traffic (and hipcc's vmcnt(0) after every reload) into K-steps whose waits are placed by hand."""
+    scratch traffic (and hipcc's vmcnt(0) after every reload) into K-steps whose waits are placed by hand; csrc/ffn_fused.hip streams
+    its weights into registers several k-slices ahead of their use (a reload's vmcnt(0) would wait for all of them)."""
     import re
     import subprocess
     from brepgen_amd import build as b
@@ -343,3 +360,13 @@ def test_scheduler_step_takes_a_device_timestep_without_reading_it():
     p = PNDMScheduler(num_train_timesteps=1000)
     p.set_timesteps(200)
     assert p._host_ts[:5] == [int(v) for v in p.timesteps[:5]] and len(p._host_ts) == 209
+
+
+def test_allgather_entry_rejects_a_null_communicator():
+    """bg_allgather (the path's one collective for hosts without torch.distributed) is exported and checks its arguments before it
+    touches RCCL: no communicator -> BG_E_ARG; zero bytes -> nothing to do."""
+    from brepgen_amd import _lib
+    lib = _lib.load()
+    assert lib.bg_allgather(None, None, 16, None, None) == -1
+    assert b"communicator" in lib.bg_last_error()
+    assert lib.bg_allgather(None, None, 0, 1, None) == 0

@@ -307,7 +307,8 @@ def _ragged_lengths(B, N, seed, lo=0):
     return n
 
 
-@pytest.mark.parametrize("B,N", [(512, 60), (37, 64), (5, 8), (300, 30)])
+# (B > 1024: the multi-pass `base += 1024` loops, the cross-wave histogram prefix and the 64-rank batches of the walk; 8192 = the bound)
+@pytest.mark.parametrize("B,N", [(512, 60), (37, 64), (5, 8), (300, 30), (1025, 60), (4096, 33), (8192, 60)])
 def test_slot_packed_compaction_matches_its_restatement(pc, B, N):
     from brepgen_amd import _lib
     n = _ragged_lengths(B, N, B + N)
@@ -328,10 +329,11 @@ def test_slot_packed_compaction_matches_its_restatement(pc, B, N):
     assert int(offs[B]) == 64 * len(slots)
     assert cnt.cpu().tolist() == n.tolist()
     sdc, sac, offc, srcc = sd.cpu().tolist(), sa.cpu().tolist(), offs.cpu().tolist(), src.cpu().tolist()
+    pm = perm_mask.tolist()                                       # (plain lists: B = 8192 would otherwise index a tensor half a million times)
     for k, (a, na, b, nb) in enumerate(slots):
         assert (sdc[2 * k], sdc[2 * k + 1], sac[k]) == (na, nb, a), k
-        valid_a = [a * N + i for i in range(N) if not perm_mask[a, i]]
-        rows = valid_a + ([b * N + i for i in range(N) if not perm_mask[b, i]] if b >= 0 else [])
+        valid_a = [a * N + i for i in range(N) if not pm[a][i]]
+        rows = valid_a + ([b * N + i for i in range(N) if not pm[b][i]] if b >= 0 else [])
         rows += [valid_a[0]] * (64 - len(rows))                   # clones of the slot's first token
         assert srcc[64 * k:64 * k + 64] == rows, k
     for b in range(B):
