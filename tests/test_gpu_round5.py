@@ -271,11 +271,12 @@ def test_exact_row_plan_skips_nothing_but_launches(pc):
                 m(*args)
         assert torch.equal(first, second) and torch.equal(first, third)
         hc = m._hint_cache
-        assert hc["counts"] is not None and (ns, True) in hc["plans"]
+        pk = (ns, (True,) * ns)                                    # (slot-packed in every sample group: the library's own predicate per group)
+        assert hc["counts"] is not None and pk in hc["plans"]
         counts = (~args[3]).sum(1).tolist()
         assert hc["counts"] == counts
         want = [m._slot_rows(counts[lo:hi]) for lo, hi in m._group_ranges(512, ns)]
-        assert list(hc["plans"][(ns, True)]) == [float(v) for v in want]
+        assert list(hc["plans"][pk]) == [float(v) for v in want]
         # the residual-stream GEMMs (24 per evaluation and group): where the rule gives every panel of the planned count to the
         # 256 x 256 kernel it runs alone, where it gives it none the pipelined 128 x 128 kernel does -- never both
         lib = _lib.load()

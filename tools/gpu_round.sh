@@ -1,6 +1,7 @@
 #!/bin/bash
-# One gpurun call: GPU tests, smoke, bench, rocprofv3 kernel stats, PMC passes, the rank-local ABC / furniture loops in full.
-# Everything lands in gpurun_out/.     bash tools/gpu_round.sh [all|test|bench|prof|pmc|ranklocal]
+# One gpurun call: GPU tests, smoke, bench (which runs the rank-local ABC / furniture loops in full itself since round 6), rocprofv3 kernel
+# stats, PMC passes on the bench's step mix, a PMC pass over the attention micro-benchmark.
+# Everything lands in gpurun_out/.     bash tools/gpu_round.sh [all|test|bench|prof|pmc|attnpmc]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
@@ -14,7 +15,7 @@ if [[ $WHAT == all || $WHAT == test ]]; then
   tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log
 fi
 if [[ $WHAT == all || $WHAT == bench ]]; then
-  timeout 900 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
+  timeout 1500 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
   tail -2 $O/bench.log | cut -c1-260
 fi
 if [[ $WHAT == all || $WHAT == prof ]]; then
@@ -42,11 +43,15 @@ if [[ $WHAT == all || $WHAT == pmc ]]; then
   done
   cd $R
 fi
-if [[ $WHAT == all || $WHAT == ranklocal ]]; then
-  for c in cfg4 cfg5; do
-    timeout 900 python tools/rank_local_bench.py $c > $O/rank_local_$c.log 2>&1; echo "rc=$?" >> $O/rank_local_$c.log
-    grep -E "loops_s|samples_per_s" $O/rank_local_$c.log
-  done
+if [[ $WHAT == all || $WHAT == attnpmc ]]; then
+  export TMPDIR=/tmp
+  cd /tmp
+  rm -rf $O/pmc_attn
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_attn -o pmc -- python $R/tools/attn_bench.py > $O/pmc_attn.log 2>&1
+  echo "pmc_attn rc=$?" >> $O/pmc_attn.log
+  cd $R
+  python tools/attn_pmc_summary.py r06 > $O/attn_pmc_summary.log 2>&1
+  cp profiles/r06/attn_pmc_per_launch_shape.json $O/ 2>/dev/null
 fi
 du -ah $O | sort -h | tail -30 > $O/listing.txt 2>&1
 find $O -type f -size +16M -print -delete >> $O/listing.txt 2>&1
