@@ -100,7 +100,6 @@ _SIGNATURES = {
     "bg_ln_silu_out_fwd": (C.c_int, [vp, fp, fp, vp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_attn_fwd": (C.c_int, [vp, u8p, vp, C.c_int, C.c_int, C.c_int, vp]),
     "bg_ffn_fused_fwd": (C.c_int, [vp, vp, fp, vp, fp, fp, vp, fp, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp]),
-    "bg_split_panel_fwd": (C.c_int, [vp, C.c_int, vp, fp, vp, vp, fp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "bg_qkv_attn_fwd": (C.c_int, [vp, vp, fp, fp, fp, u8p, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_qkv_attn_paired_fwd": (C.c_int, [vp, vp, fp, fp, fp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "bg_compact_rows_paired": (C.c_int, [u8p, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbrepgen_hip.so")
-SOURCES = ["elementwise.hip", "embed.hip", "gemm_f32.hip", "gemm_16bit.hip", "gemm_p256.hip", "gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip", "split_panel.hip", "out_tail.hip", "attn.hip", "vae.hip", "dedup.hip", "chamfer.hip", "rng.hip", "compact.hip", "vae_exec.hip", "collective.hip", "denoiser.hip"]
+SOURCES = ["elementwise.hip", "embed.hip", "gemm_f32.hip", "gemm_16bit.hip", "gemm_p256.hip", "gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip", "out_tail.hip", "attn.hip", "vae.hip", "dedup.hip", "chamfer.hip", "rng.hip", "compact.hip", "vae_exec.hip", "collective.hip", "denoiser.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -21,7 +21,7 @@ int launch_status(const char* what);   // hipGetLastError -> 0 / positive hipErr
 
 // ---- optional per-kernel timing (bg_profile_begin / bg_profile_end; off by default, zero cost when off) ----
 enum ProfKernel { PK_GEMM_BF16_128 = 0,  /* persistent 128x128 kernel (gemm_bf16_p_kernel) */ PK_GEMM_BF16_64, PK_GEMM_F32, PK_ATTN_BF16, PK_ATTN_F32, PK_LAYERNORM,
-                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_OUT_TAIL, PK_FFN_FUSED, PK_SPLIT_PANEL, PK_COUNT };
+                  PK_DDPM_STEP, PK_PNDM_STEP, PK_MISC, PK_EMBED, PK_GEMM_P256, PK_GEMM_SPLIT, PK_GEMM_P256_SPLIT, PK_QKV_ATTN, PK_OUT_TAIL, PK_FFN_FUSED, PK_COUNT };
 extern bool g_prof_on;
 void prof_pre(hipStream_t s);
 void prof_post(int kernel, double flops, double bytes, hipStream_t s);
@@ -36,7 +36,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
 //  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold; 16: 1 = FFN1 and FFN2 as two launches even where w_1f / w_2f are given -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_SPLIT_PANEL = 19, TUNE_COUNT = 20 };
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_COUNT = 19 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -313,15 +313,6 @@ struct FfnArgs {
     float ln_eps;
     long long* stamps = nullptr;        // measurement aid (bg_tune keys 17 / 18 = a device address): s_memtime of workgroup 0's phases
 };
-// out-proj / FFN2 (split residual in place + statistics) on 64-row panels, weights streamed into registers (split_panel.hip; experiment)
-struct SplitPanelArgs {
-    const void* a; const void* wf; const float* bias;    // a [M, K] 16-bit rows; W [768, K] in fragment order; bias [768]
-    void* xh; void* xl; float* stats;                    // residual planes (in place), statistics out [12][m_stride][2]
-    int M, m_stride, K;
-    const int* m_dev;
-};
-bool split_panel_eligible(const SplitPanelArgs& g, int dtype);
-int split_panel(const SplitPanelArgs& g, int dtype, hipStream_t s, double rows_hint);
 bool ffn_fused_eligible(const FfnArgs& g, int dtype);
 int ffn_fused(const FfnArgs& g, int dtype, hipStream_t s, double rows_hint);
 // out = f32 -> bf16 cast (n elements, n % 4 == 0)

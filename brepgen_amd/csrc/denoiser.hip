@@ -37,7 +37,7 @@ bool g_open = false;
 const char* const kProfNames[PK_COUNT] = {"gemm16_persistent_kernel(128x128)", "gemm16_kernel(generic: 128x64 / 64x64 tiles)", "gemm_f32", "attn16_kernel", "attn_f32_kernel",
                                           "ln768_kernel", "ddpm_step_kernel", "pndm_step_kernel", "misc", "embed_ln_silu_kernel", "gemm16_p256_kernel(256x256)",
                                           "gemm16_split_pipe_kernel(128x128)", "gemm16_p256_kernel(256x256, split-residual launches)",
-                                          "qkv_attn_kernel(256x192 + attention)", "ln_silu_out_kernel", "ffn_fused_kernel(64-row panels)", "split_panel_kernel(64-row panels)"};
+                                          "qkv_attn_kernel(256x192 + attention)", "ln_silu_out_kernel", "ffn_fused_kernel(64-row panels)"};
 }  // namespace
 
 void prof_pre(hipStream_t s) {

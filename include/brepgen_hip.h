@@ -154,13 +154,6 @@ int bg_qkv_attn_fwd(const void* x_hi, const void* w_qkv, const float* bias, cons
 int bg_ffn_fused_fwd(void* x_hi, void* x_lo, float* stats, const void* w1_frag, const float* b1, const float* colsum1,
                      const void* w2_frag, const float* b2, int M, int m_stride, const int* m_dev, int dtype, float ln_eps,
                      bg_stream_t stream);
-/* EXPERIMENT (round 6; not used by bg_denoiser_fwd unless bg_tune key 19 = 1 and the weights carry fragment-order copies): out-proj / FFN2
- * of an encoder layer -- the split-residual GEMM, in place, with row statistics -- on 64-row panels with the weights streamed into
- * registers (csrc/split_panel.hip).  a [M, K] 16-bit rows (K = 768 | 1024), w_frag = W [768, K] in the fragment order of
- * bg_layer_weights.w_2f, bias [768]; x_hi / x_lo / stats as bg_ffn_fused_fwd's.  Bit for bit what bg_gemm_ex_fwd (split residual +
- * statistics) produces. */
-int bg_split_panel_fwd(const void* a, int K, const void* w_frag, const float* bias, void* x_hi, void* x_lo, float* stats, int M,
-                       int m_stride, const int* m_dev, int dtype, bg_stream_t stream);
 /* The same launch on a SLOT-PACKED ragged batch (bg_compact_rows_paired): *m_dev rows (device-side, a multiple of 64) in 64-row
  * slots of one or two whole samples, slot_desc[2 k] / [2 k + 1] their lengths, at most slot_bound slots; m_stats = row stride of
  * stats_in.  out rows = what bg_gemm_ex_fwd + bg_attn_varlen_fwd produce for the same samples on the dense packing, bit for bit.

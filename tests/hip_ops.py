@@ -215,16 +215,3 @@ def ffn_fused(hi, lo, stats, w1, b1, colsum1, w2, b2, m_dev=None, ln_eps=1e-5):
           "bg_ffn_fused_fwd")
     return hi, lo, stats
 
-
-def split_panel(a, w, bias, hi, lo, stats_stride=None, m_dev=None):
-    """bg_split_panel_fwd: the split-residual GEMM (in place on clones of hi / lo) on 64-row panels; w [768, K] row-major (fragment order is
-    made here by the product's packer).  Returns (hi, lo, stats [12, M, 2])."""
-    from brepgen_amd.network import ffn_fragment_order
-    _need_cuda(a, w, bias, hi, lo)
-    hi, lo = hi.clone(), lo.clone()
-    M, K = a.shape
-    stats = torch.zeros(12, stats_stride or M, 2, device=a.device, dtype=torch.float32)
-    wf = ffn_fragment_order(w.contiguous(), 3)
-    check(_lib.load().bg_split_panel_fwd(ptr(a.contiguous()), K, ptr(wf), ptr(bias.contiguous()), ptr(hi), ptr(lo), ptr(stats), M, stats.shape[1],
-                                         ptr(m_dev), bg_dtype(a.dtype), stream()), "bg_split_panel_fwd")
-    return hi, lo, stats

@@ -91,38 +91,7 @@ def stamps(M=30720):
         print("panel", k // n, "cycles:", " | ".join(f"{names[i]} {seg[i + 1] - seg[i]}" for i in range(n) if seg[i + 1] and seg[i]), "| total", seg[n - 1] - seg[0])
 
 
-def split_panel():
-    """bg_split_panel_fwd against the library's own choice for the same split-residual GEMM (out-proj K = 768, FFN2 K = 1024)."""
-    lib = _lib.load()
-    dt = torch.bfloat16
-    code = ops.bg_dtype(dt)
-    for K in (768, 1024):
-        for M in (15360, 18432, 30720, 61440, 138752):
-            g = torch.Generator().manual_seed(1)
-            x = torch.randn(M, 768, generator=g)
-            hi = x.to(dt).cuda()
-            lo = (x - hi.cpu().float()).to(dt).cuda()
-            a = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
-            w = (torch.randn(768, K, generator=g) / K ** 0.5).to(dt).cuda()
-            b = (0.1 * torch.randn(768, generator=g)).cuda()
-            stats = torch.zeros(12, M, 2, device="cuda")
-            wf = ffn_fragment_order(w, 3)
-            d2 = _lib.GemmDesc()
-            d2.a, d2.lda, d2.w, d2.bias, d2.out, d2.ldc = ptr(a), K, ptr(w), ptr(b), ptr(hi), 768
-            d2.M, d2.N, d2.N_pad, d2.K = M, 768, 768, K
-            d2.ab_dtype, d2.out_dtype, d2.act = code, code, 0
-            d2.out_lo, d2.res_hi, d2.res_lo, d2.ld_res, d2.stats_out, d2.ln_eps = ptr(lo), ptr(hi), ptr(lo), 768, ptr(stats), 1e-5
-            panel = lambda: check(lib.bg_split_panel_fwd(ptr(a), K, ptr(wf), ptr(b), ptr(hi), ptr(lo), ptr(stats), M, M, None, code, stream()), "panel")
-            gemm = lambda: check(lib.bg_gemm_ex_fwd(d2, stream()), "gemm")
-            tp, tg = timed(panel), timed(gemm)
-            fl = 2.0 * M * 768 * K
-            print(f"K={K:5d} M={M:7d}  panel kernel {tp:7.1f} us = {fl / tp / 1e6:5.0f} TF   library's split-residual GEMM {tg:7.1f} us = {fl / tg / 1e6:5.0f} TF", flush=True)
-
-
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "split_panel":
-        split_panel()
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stamps":
         stamps()
         sys.exit(0)
