@@ -463,23 +463,24 @@ def rank_local_extra(name, k=None):
 
 def torch_eager_extra(dev, steps=10, warmup=3):
     """The like-for-like "reference PyTorch on this GPU" figure: the reference's formulation of
-    SurfZNet (oracle/ref_formulation.py: stock nn.TransformerEncoder seq-first, as network.py:1133-1200 composes it) through
-    torch-ROCm EAGER on this device -- fp32 and under torch.autocast (fp16: what sample.py:121 runs; bf16: the bench's dtype) --
-    one eps-evaluation at the headline's loop-C shape (512 x 60, key-padding mask) + the scheduler update in torch ops."""
-    from oracle import denoisers as orc
-    from oracle import ref_formulation as rf
-    net = rf.build("SurfZNet", orc.seeded_state_dict("SurfZNet", 0)).to(dev).eval()
+    SurfZNet -- stock torch.nn blocks composed as network.py:1133-1200 composes them (tools/torch_eager_baseline.py: EagerSurfZ; no
+    oracle, no reference import, random-init weights) -- through torch-ROCm EAGER on this device, fp32 and under torch.autocast (fp16:
+    what sample.py:121 runs; bf16: the bench's dtype): one eps-evaluation at the headline's loop-C shape (512 x 60, key-padding mask)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from torch_eager_baseline import EagerSurfZ
+    torch.manual_seed(0)
+    net = EagerSurfZ().to(dev).eval()
     z, pos, mask = (t.to(dev) for t in make_inputs(B_PER_GPU, "cpu", 1234))
-    t = torch.tensor([249], device=dev)
-    out = {"workload": "SurfZNet eps-evaluation, 512 x 60 tokens + key-padding mask, dense (as the reference runs it), torch-ROCm eager",
-           "torch": torch.__version__}
+    t = torch.full((B_PER_GPU,), 249, device=dev, dtype=torch.long)
+    out = {"workload": "SurfZNet eps-evaluation, 512 x 60 tokens + key-padding mask, dense (as the reference runs it), torch-ROCm eager of "
+                       "stock nn.TransformerEncoder (tools/torch_eager_baseline.py)", "torch": torch.__version__}
     for name, dt in (("autocast_bf16", torch.bfloat16), ("autocast_fp16", torch.float16), ("fp32", None)):
         def fn():
             with torch.no_grad():
                 if dt is None:
-                    return net(z, t, pos, mask, None)
+                    return net(z, t, pos, mask)
                 with torch.autocast("cuda", dtype=dt):
-                    return net(z, t, pos, mask, None)
+                    return net(z, t, pos, mask)
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()
