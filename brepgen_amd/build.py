@@ -15,7 +15,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libbrepgen_hip.so")
 SOURCES = ["elementwise.hip", "embed.hip", "gemm_f32.hip", "gemm_16bit.hip", "gemm_p256.hip", "gemm_split.hip", "qkv_attn.hip", "ffn_fused.hip", "out_tail.hip", "attn.hip", "vae.hip", "dedup.hip", "chamfer.hip", "rng.hip", "compact.hip", "vae_exec.hip", "collective.hip", "denoiser.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+PER_FILE_FLAGS = {}
+# -fno-slp-vectorize: hipcc's SLP vectoriser turns adjacent scalar fp32 arithmetic into PACKED fp32 VALU instructions with op_sel broadcast
+# modifiers (v_pk_add_f32 ... op_sel_hi:[1,0], v_pk_mul_f32 ... op_sel:[0,1]).  On gfx950 (ROCm 7.2) a wave executing those returns WRONG values
+# in its lanes 48-63 while another wave on the same SIMD -- of ANY kernel, e.g. this library's GEMMs on a second stream -- mixes MFMA with LDS-DMA
+# (global_load_lds): found in round 6 (GroupNorm passes of a VAE decode corrupted by a concurrent VAE decode), reproduced stand-alone by
+# tools/pk_f32_mfma_hazard_probe.hip (profiles/r06/pk_f32_mfma_lds_dma_hazard_probe.log).  Without the vectoriser no kernel of the library
+# contains such an instruction (tests/test_abi_cpu.py scans the ISA); packed f32 is an anti-lever beside MFMAs anyway (CDNA guide).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -43,7 +50,7 @@ def _digest():
     for f in files:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items()))).encode())
     # the compiler is part of the build: the kernels that run at the 256-VGPR limit (gemm_p256.hip, gemm_split.hip) are checked for
     # spills with THIS hipcc (tests/test_abi_cpu.py); another version has to rebuild -- and re-run that check
     # (no hipcc on this box: the digest then covers the sources only -- see build())
@@ -56,7 +63,7 @@ def _digest():
 
 def _compile(src, extra):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    cmd = [_hipcc(), *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *PER_FILE_FLAGS.get(src, []), *extra, "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -158,17 +158,43 @@ def dedup_edges(edgePos, surfMask, threshold):
 
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def decode_latents(surf_vae, edge_vae, latents):
+def decode_latents(surf_vae, edge_vae, latents, concurrent=True):
     """Stage 5 of sample.py (lines 286-294): VAE-decode the cascade's latents on the device.
 
     latents: the dict CascadeSampler.sample returns.  Adds surf_ncs [B,S,32,32,3], edge_ncs [B,S,E,32,3] and
     edgeV [B,S,E,6] (the vertex half of edgeZV, sample.py:286) and returns the dict.  The token layout of the latents
     (position-major, channel-minor) is the channels-last layout of the VAE kernels, so no permutes are needed."""
     out = dict(latents)
-    out["surf_ncs"] = surf_vae.decode_tokens(latents["surfZ"])
-    out["edge_ncs"] = edge_vae.decode_tokens(latents["edgeZV"][..., :12])
+    surf_z, edge_z = latents["surfZ"], latents["edgeZV"][..., :12]
+    if concurrent and surf_z.is_cuda and surf_z.numel() and edge_z.numel():
+        # The two decodes are independent: the edge pass runs on a forked stream beside the surface pass and is joined before the
+        # function returns (same kernels, same results).  Each pass alternates MFMA-bound convolutions with HBM-bound GroupNorm /
+        # activation passes and tile-round tails; two of them in flight fill each other's gaps (the n_split of the denoisers).
+        cur = torch.cuda.current_stream(surf_z.device)
+        side = _side_stream(surf_z.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            edge = edge_vae.decode_tokens(edge_z)
+        out["surf_ncs"] = surf_vae.decode_tokens(surf_z)
+        cur.wait_stream(side)
+        edge.record_stream(cur)                       # allocated on the side stream, consumed on the caller's
+        out["edge_ncs"] = edge
+    else:
+        out["surf_ncs"] = surf_vae.decode_tokens(surf_z)
+        out["edge_ncs"] = edge_vae.decode_tokens(edge_z)
     out["edgeV"] = latents["edgeZV"][..., 12:].contiguous()
     return out
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One helper stream per device for decode_latents' forked pass (created once: a stream per call would leak handles)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return _SIDE_STREAMS[key]
 
 
 class _GraphedEval:

@@ -183,8 +183,9 @@ def test_p256_kernels_do_not_spill():
     """csrc/gemm_p256.hip keeps LDS-DMA in flight across its whole K loop with hand-counted vmcnt waits; a register spill would
     put scratch loads (vector-memory operations hipcc follows with vmcnt(0)) into that stream -- the pipeline would drain at
     every reload, and a spilled destination of the split epilogue's inline-asm residual loads would be read before it lands.
-    The build must therefore stay spill-free: 0 bytes of scratch for the plain / LayerNorm-fold kernels, at most one
-    loop-invariant dword for the split-residual ones."""
+    The build must therefore stay spill-free: 0 bytes of scratch for the plain / LayerNorm-fold kernels, at most three
+    loop-invariant dwords for the split-residual ones (one before round 6's -fno-slp-vectorize build; the reloads sit in the epilogue,
+    and the scan below checks that none of them is a destination of the asm loads)."""
     import re
     import subprocess
     from brepgen_amd import build as b
@@ -199,7 +200,7 @@ def test_p256_kernels_do_not_spill():
         if "gemm16_p256_kernel" not in n:
             continue
         split = "ELi3E" in n                                     # MODE = P_SPLIT in the mangled name
-        assert sc <= (8 if split else 0), (n, sc)
+        assert sc <= (16 if split else 0), (n, sc)
     # ... and the one dword the split-residual kernels may spill must not be a destination of their inline-asm residual loads (those
     # are invisible to hipcc's wait insertion: a spilled or reloaded destination would be read before the counted wait covers it).
     # In the -S output the asm loads sit between ;;#ASMSTART / ;;#ASMEND markers; every scratch access names its register.
@@ -370,3 +371,23 @@ def test_allgather_entry_rejects_a_null_communicator():
     assert lib.bg_allgather(None, None, 16, None, None) == -1
     assert b"communicator" in lib.bg_last_error()
     assert lib.bg_allgather(None, None, 0, 1, None) == 0
+
+
+def test_no_kernel_contains_op_sel_modified_packed_fp32():
+    """gfx950 hazard found in round 6 (brepgen_amd/build.py: FLAGS): packed-fp32 VALU instructions with op_sel modifiers compute wrong
+    values in lanes 48-63 while another wave on the SIMD mixes MFMA with LDS-DMA -- which is what every 16-bit GEMM / attention kernel
+    of this library does, on a second stream whenever sample groups (n_split) or the two VAE decodes run concurrently.  The build
+    therefore must not contain such instructions: scan the ISA of every source."""
+    import re
+    import subprocess
+    from brepgen_amd import build as b
+    assert "-fno-slp-vectorize" in b.FLAGS
+    bad = {}
+    for src in b.SOURCES:
+        r = subprocess.run([b._hipcc(), *b.FLAGS, *b.PER_FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", "-c", os.path.join(b.CSRC, src), "-o", "-"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hits = [l.strip() for l in r.stdout.splitlines() if re.search(r"\bv_pk_\w+_f32\b.*\bop_sel", l)]
+        if hits:
+            bad[src] = hits[:3]
+    assert not bad, bad
