@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, WPH == 1 ? 2 : 4) void attn16_kernel(const voi
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = dt * 32 + 8 * g4 + 4 * h;
                 V4 pk;
-                pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
-                pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
+                pk[0] = cvt16<T>(o[dt][4 * g4 + 0] * inv); pk[1] = cvt16<T>(o[dt][4 * g4 + 1] * inv);
+                pk[2] = cvt16<T>(o[dt][4 * g4 + 2] * inv); pk[3] = cvt16<T>(o[dt][4 * g4 + 3] * inv);
                 *reinterpret_cast<V4*>(op + d) = pk;
             }
     }
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = dt * 32 + 8 * g4 + 4 * h;
                 V4 pk;
-                pk[0] = (T)(o[dt][4 * g4 + 0] * inv); pk[1] = (T)(o[dt][4 * g4 + 1] * inv);
-                pk[2] = (T)(o[dt][4 * g4 + 2] * inv); pk[3] = (T)(o[dt][4 * g4 + 3] * inv);
+                pk[0] = cvt16<T>(o[dt][4 * g4 + 0] * inv); pk[1] = cvt16<T>(o[dt][4 * g4 + 1] * inv);
+                pk[2] = cvt16<T>(o[dt][4 * g4 + 2] * inv); pk[3] = cvt16<T>(o[dt][4 * g4 + 3] * inv);
                 *reinterpret_cast<V4*>(op + d) = pk;
             }
     }

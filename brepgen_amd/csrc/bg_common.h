@@ -70,9 +70,20 @@ __device__ __forceinline__ bf16x4 to_bf16x4(float a, float b, float c, float d) 
 // 4 floats -> 4 packed 16-bit values of dtype `dt` (BG_BF16 | BG_F16), as a 64-bit payload
 __device__ __forceinline__ uint2 pack4_16(float a, float b, float c, float d, int dt) {
     union { bf16x4 b; half4_t h; uint2 u; } r;
-    if (dt == BG_F16) { r.h[0] = (_Float16)a; r.h[1] = (_Float16)b; r.h[2] = (_Float16)c; r.h[3] = (_Float16)d; }
+    if (dt == BG_F16) {
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // no fma + conversion fusion (v_fma_mixlo_f16: one rounding): see gemm16.h
+        r.h[0] = (_Float16)a; r.h[1] = (_Float16)b; r.h[2] = (_Float16)c; r.h[3] = (_Float16)d;
+    }
     else r.b = to_bf16x4(a, b, c, d);
     return r.u;
+}
+
+// fp32 -> 16-bit with the value made opaque first when the target is fp16: hipcc otherwise fuses a preceding multiply / fma with the
+// conversion into v_fma_mixlo_f16 (ONE rounding instead of two) in some kernels and not in others, which breaks the bit-identity of
+// kernels that compute the same thing (gemm16.h Elem<true>::pack4; seen in round 6 when the build flags changed)
+template <typename T> __device__ __forceinline__ T cvt16(float x) {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, __bf16)) asm volatile("" : "+v"(x));
+    return (T)x;
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

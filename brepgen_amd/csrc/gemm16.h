@@ -22,6 +22,10 @@ template <> struct Elem<true> {
     using T = _Float16; using V8 = f16x8; using V4 = f16x4;
     static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ V4 pack4(float a, float b, float c, float d) {
+        // the fp32 values are made opaque first: where they come straight out of an fma, hipcc would otherwise fuse fma + conversion
+        // into v_fma_mixlo_f16 (ONE rounding) in some kernels and not in others, and the GEMM kernels would differ by an ulp in ~10 ppm
+        // of the fp16 values (seen between the 256 x 256 and the 128 x 128 kernel once the build flags changed in round 6)
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
         V4 r; r[0] = (_Float16)a; r[1] = (_Float16)b; r[2] = (_Float16)c; r[3] = (_Float16)d; return r;
     }
 };

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm16_kernel(GemmArgs g) {
                 float o = vv[e];
                 if (g.add) o += g.add[(size_t)(arow1 / g.add_div) * g.ld_add + col];
                 if (g.add2) o += g.add2[(size_t)(arow2 / g.add2_div) * g.ld_add2 + col];
+                asm volatile("" : "+v"(o));                               // (no add + fp16-conversion fusion)
                 if (g.out_dtype != BG_F32) reinterpret_cast<T*>(g.out)[(size_t)orow * g.ldc + col] = (T)o;
                 else reinterpret_cast<float*>(g.out)[(size_t)orow * g.ldc + col] = o;
             }
@@ -626,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                         // neighbour exchange inside lane pairs: DPP quad_perm [1,0,3,2] (pure VALU, no LDS crossbar)
                         const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
                             0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
-                        const float lo = (lane & 1) ? recv : a, hi = (lane & 1) ? b : recv;
+                        float lo = (lane & 1) ? recv : a, hi = (lane & 1) ? b : recv;
+                        asm volatile("" : "+v"(lo), "+v"(hi));       // (no fma + fp16-conversion fusion: gemm16.h Elem<true>::pack4)
                         const int r = 2 * rp + (lane & 1);
                         const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
                         union { T v[2]; unsigned u; } pk;

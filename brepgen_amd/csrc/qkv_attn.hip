@@ -528,10 +528,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs g) {
 #pragma unroll
                         for (int k2 = 0; k2 < 2; ++k2) {
                             union { V4 v; unsigned u[2]; } q0, q1;
-                            q0.v[0] = (T)(o[dt][8 * k2 + 0] * inv); q0.v[1] = (T)(o[dt][8 * k2 + 1] * inv);
-                            q0.v[2] = (T)(o[dt][8 * k2 + 2] * inv); q0.v[3] = (T)(o[dt][8 * k2 + 3] * inv);
-                            q1.v[0] = (T)(o[dt][8 * k2 + 4] * inv); q1.v[1] = (T)(o[dt][8 * k2 + 5] * inv);
-                            q1.v[2] = (T)(o[dt][8 * k2 + 6] * inv); q1.v[3] = (T)(o[dt][8 * k2 + 7] * inv);
+                            q0.v[0] = cvt16<T>(o[dt][8 * k2 + 0] * inv); q0.v[1] = cvt16<T>(o[dt][8 * k2 + 1] * inv);
+                            q0.v[2] = cvt16<T>(o[dt][8 * k2 + 2] * inv); q0.v[3] = cvt16<T>(o[dt][8 * k2 + 3] * inv);
+                            q1.v[0] = cvt16<T>(o[dt][8 * k2 + 4] * inv); q1.v[1] = cvt16<T>(o[dt][8 * k2 + 5] * inv);
+                            q1.v[2] = cvt16<T>(o[dt][8 * k2 + 6] * inv); q1.v[3] = cvt16<T>(o[dt][8 * k2 + 7] * inv);
                             // swap: (q0 of the upper half) <-> (q1 of the lower half): lanes < 32 end with quads (2 k2, h = 0 | 1), lanes >= 32
                             // with quads (2 k2 + 1, h = 0 | 1)
                             const auto w0 = __builtin_amdgcn_permlane32_swap(q0.u[0], q1.u[0], false, false);

@@ -45,6 +45,38 @@ __global__ __launch_bounds__(256) void victim(VArgs a) {
     }
 }
 
+// the same arithmetic as ONE instruction pair in inline asm on register operands (no memory traffic in the victim): which instruction form
+// is the vulnerable one?  OPSEL: v_pk_add_f32 / v_pk_mul_f32 with the op_sel broadcast modifiers; otherwise plain packed ops on
+// pre-broadcast operands.  Compared in-kernel with scalar v_sub_f32 / v_mul_f32; mismatches counted per 16-lane quarter.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <bool OPSEL>
+__global__ __launch_bounds__(256) void victim_asm(unsigned* bad_per_quarter, int iters) {
+    const int lane = threadIdx.x & 63;
+    unsigned bad = 0;
+    float seed = 0.37f * (float)(blockIdx.x * 256 + threadIdx.x) + 1.0f;
+    for (int it = 0; it < iters; ++it) {
+        seed = seed * 1.000173f + 0.013f;
+        f32x2 x = {seed, seed * 0.5f - 3.0f};
+        f32x2 p = {seed * 0.25f + (float)(lane >> 2), 1.0f + 0.001f * (float)lane};
+        f32x2 d, y;
+        if (OPSEL) {
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(p));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(y) : "v"(d), "v"(p));
+        } else {
+            f32x2 pm = {p.x, p.x}, pr = {p.y, p.y};
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(x), "v"(pm));
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(d), "v"(pr));
+        }
+        float r0, r1;
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(x.x), "v"(p.x));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(x.y), "v"(p.x));
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r0) : "v"(p.y));
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r1) : "v"(p.y));
+        bad += (__float_as_uint(y.x) != __float_as_uint(r0)) + (__float_as_uint(y.y) != __float_as_uint(r1));
+    }
+    if (bad) atomicAdd(&bad_per_quarter[lane >> 4], bad);
+}
+
 template <int KIND>      // 1 MFMA, 2 LDS-DMA, 3 both, 4 v_fma
 __global__ __launch_bounds__(256) void disturber(const unsigned char* src, float* sink, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[32768];
@@ -119,6 +151,25 @@ int main() {
                 if (got[i] != ref[i]) bad[((i / 4) % 64) / 16]++;       // lane of the float4's thread inside its wave
         }
         printf("victim beside %-34s: mismatching elements by lane quarter (0-15, 16-31, 32-47, 48-63): %u %u %u %u\n", names[kind], bad[0], bad[1], bad[2], bad[3]);
+    }
+    // register-only victims beside the MFMA + LDS-DMA disturber
+    unsigned* d_bad;
+    hipMalloc(&d_bad, 16);
+    for (int form = 0; form < 2; ++form) {
+        unsigned tot[4] = {0, 0, 0, 0};
+        for (int rep = 0; rep < 5; ++rep) {
+            hipMemset(d_bad, 0, 16);
+            hipDeviceSynchronize();
+            hipLaunchKernelGGL((disturber<3>), dim3(1024), dim3(256), 0, s1, dsrc, dsink, 3000);
+            if (form == 0) hipLaunchKernelGGL((victim_asm<true>), dim3(2048), dim3(256), 0, s0, d_bad, 4000);
+            else hipLaunchKernelGGL((victim_asm<false>), dim3(2048), dim3(256), 0, s0, d_bad, 4000);
+            hipDeviceSynchronize();
+            unsigned h[4];
+            hipMemcpy(h, d_bad, 16, hipMemcpyDeviceToHost);
+            for (int q = 0; q < 4; ++q) tot[q] += h[q];
+        }
+        printf("register-only victim, %-28s beside MFMA + LDS-DMA: mismatches by lane quarter: %u %u %u %u\n",
+               form == 0 ? "op_sel packed f32 (inline asm)" : "plain packed f32 (inline asm)", tot[0], tot[1], tot[2], tot[3]);
     }
     return 0;
 }
