@@ -237,6 +237,7 @@ class _Program:
 
 class _HipVAE(nn.Module):
     WS_BUDGET = 8 << 30            # bytes of bg_vae_run workspace (activation slots + scratch) per chunk of samples
+    TWO_STREAMS_MIN = 2048         # samples from which a pass is cut into two concurrent halves (below: launch-bound, nothing to overlap)
 
     def __init__(self):
         super().__init__()
@@ -249,6 +250,8 @@ class _HipVAE(nn.Module):
         self._programs = {}
         self._zero = None
         self._ws = {}                  # (device, stream) -> workspace kept between passes (a fresh multi-GiB hipMalloc costs more than the pass)
+        self.two_streams = True        # large batches: two halves of a pass in flight on forked streams (bit-identical; _run)
+        self._side = None
 
     def _apply(self, fn, *a, **k):
         self._packs, self._programs, self._ws = {}, {}, {}
@@ -275,13 +278,39 @@ class _HipVAE(nn.Module):
         return self._zero
 
     def _run(self, x_cl, out_shape, dt):
-        """bg_vae_run over the whole batch x_cl [n, (H,) W, C] -> [n, *out_shape]; chunks sized to WS_BUDGET."""
+        """bg_vae_run over the whole batch x_cl [n, (H,) W, C] -> [n, *out_shape]; chunks sized to WS_BUDGET.  Large batches are cut into
+        two halves that run CONCURRENTLY -- the first on the caller's stream, the second on a forked helper stream, joined before the
+        call returns (`two_streams`; each stream has its own workspace): a pass alternates MFMA-bound convolutions with HBM-bound
+        GroupNorm / activation passes and tile-round tails, and two of them in flight fill each other's gaps, exactly like the sample
+        groups of the denoisers (n_split).  Samples are independent and chunk boundaries do not change a sample's bits (tests), so
+        the result is bit-identical."""
         if dt not in self._programs:
             self._programs[dt] = self._program(_Program(), self._pack(dt)).finish()
+        n = x_cl.shape[0]
+        out = torch.empty(n, *out_shape, device=x_cl.device, dtype=torch.float32)
+        self._zero_page(x_cl.device)                                    # (created on the caller's stream, BEFORE the fork below orders the helper behind it)
+        if self.two_streams and n >= self.TWO_STREAMS_MIN and not torch.cuda.is_current_stream_capturing():
+            h = (n // 2 + 63) // 64 * 64                                # (whole 64-sample groups per half)
+            cur = torch.cuda.current_stream(x_cl.device)
+            side = self._side_stream(x_cl.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self._run_into(x_cl[h:], out[h:], dt)
+            self._run_into(x_cl[:h], out[:h], dt)
+            cur.wait_stream(side)
+        else:
+            self._run_into(x_cl, out, dt)
+        return out
+
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _run_into(self, x_cl, out, dt):
         pg, lib = self._programs[dt], _lib.load()
         n = x_cl.shape[0]
         h, w, c = (1, *x_cl.shape[1:]) if x_cl.dim() == 3 else x_cl.shape[1:]
-        out = torch.empty(n, *out_shape, device=x_cl.device, dtype=torch.float32)
         size = lambda n_, chunk: lib.bg_vae_workspace_bytes(pg.ops, len(pg.steps), pg.n_slots, h, w, c, n_, chunk)
         ref = min(n, 4096)
         per_sample = max(1, size(ref, ref) // ref)
@@ -296,7 +325,6 @@ class _HipVAE(nn.Module):
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=x_cl.device)
         check(lib.bg_vae_run(pg.ops, len(pg.steps), pg.n_slots, h, w, c, ptr(x_cl), n, chunk, ptr(out),
                              ptr(self._zero_page(x_cl.device)), ptr(ws), ws.numel(), stream()), "bg_vae_run")
-        return out
 
     def _dtype(self):
         if self.compute_dtype is not None:

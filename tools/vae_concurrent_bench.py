@@ -20,10 +20,11 @@ edge = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).cuda().eval()
 surf.compute_dtype = edge.compute_dtype = torch.bfloat16
 B, S, E = (256, 60, 30) if len(sys.argv) < 4 else (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]))
 lat = {"surfZ": torch.randn(B, S, 48, device="cuda"), "edgeZV": torch.randn(B, S, E, 18, device="cuda")}
-res = {"sequential": [], "concurrent": []}
+res = {"sequential": [], "concurrent": [], "concurrent + two halves per pass": []}
 with torch.no_grad():
     for rnd in range(4):
-        for name, flag in (("sequential", False), ("concurrent", True)):
+        for name, flag, halves in (("sequential", False, False), ("concurrent", True, False), ("concurrent + two halves per pass", True, True)):
+            surf.two_streams = edge.two_streams = halves
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = decode_latents(surf, edge, lat, concurrent=flag)
