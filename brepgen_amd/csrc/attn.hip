@@ -269,9 +269,13 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
 
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware walk: consecutive logical ids (the query blocks of one (sample, head)) share an XCD
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int qb = L % nqb, head = (L / nqb) % BG_N_HEAD, b = L / (nqb * BG_N_HEAD);
+    // XCD-aware walk (block id % 8 = XCD): the query blocks of one (sample, head) UNIT run back to back on one XCD -- they share
+    // that unit's K / V in its L2 -- and the units go round-robin over the XCDs, so that every XCD gets 1.5 heads of EVERY sample.
+    // (Until round 6 each XCD walked a contiguous eighth of the batch: with ragged samples the XCDs' shares of sum n_b^2 differed
+    // by +- 15 % at the bench's edge batches and the launch lasted as long as the heaviest eighth.)
+    const int unit = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7), qb = (int)(blockIdx.x >> 3) % nqb;
+    if (unit >= B * BG_N_HEAD) return;                   // (grid padded to whole rounds of 8 units)
+    const int head = unit % BG_N_HEAD, b = unit / BG_N_HEAD;
     size_t row_base = (size_t)b * N;
     if (offsets) {                                       // compacted batch: rows offsets[b] .. offsets[b+1]-1, all valid keys
         row_base = (size_t)offsets[b];
@@ -566,7 +570,7 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             else hipLaunchKernelGGL((attn16_kernel<4, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, offsets);
         } else {
             const int nqb = (N + 127) / 128;
-            const dim3 grid(nqb * BG_N_HEAD * B);
+            const dim3 grid((unsigned)(nqb * 8 * ((B * BG_N_HEAD + 7) / 8)));
             const bool masked = key_pad != nullptr && offsets == nullptr;
             if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
             else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
