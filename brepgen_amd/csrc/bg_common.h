@@ -36,7 +36,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
 //  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold; 16: 1 = FFN1 and FFN2 as two launches even where w_1f / w_2f are given -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_COUNT = 19 };
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_VAE_GN1_FUSED = 19, TUNE_COUNT = 20 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------
@@ -276,6 +276,10 @@ int layernorm768_split(const void* hi, const void* lo, const float* g, const flo
                        float eps, hipStream_t s, const int* m_dev = nullptr, double rows_hint = 0.0);
 // h = SiLU(LayerNorm(x W0^T + b0)) for k in {6, 12, 48}; w0p = W0 in MFMA operand order (embed.hip)
 bool embed_ln_silu_supported(int k);
+// vae.hip: GroupNorm(1 group) + activation (+ add) + cast of small samples in one pass (bit-identical to bg_groupnorm_stats + bg_im2col 1x1)
+bool gn1_norm_act_supported(int P, int C);
+int gn1_norm_act(const float* x, void* out, int out_dtype, int S, int P, int C, const float* gamma, const float* beta, float eps,
+                 int act, const float* add, hipStream_t s);
 // (m_dev / src_row: compacted batches -- *m_dev rows exist, row r reads x[src_row[r]])
 int embed_ln_silu(const float* x, int lda, int rows, int k, const float* w0p, const float* b0, const float* g,
                   const float* b, void* out, int out_dtype, float eps, hipStream_t s, const int* m_dev = nullptr,

@@ -208,6 +208,92 @@ __global__ __launch_bounds__(256) void norm_act_kernel(Im2colArgs a, unsigned to
     }
 }
 
+// ---- GroupNorm(1 group) + activation (+ add) + cast of SMALL samples in ONE pass: the 1-D VAE's blocks normalise whole samples of
+// 2048 / 4096 values (diffusers' ResConvBlock / SelfAttention1d: GroupNorm(1, C) over [L, C], L = 4 .. 32).  One wave per sample
+// holds it in registers (NV float4 per lane), so the tensor is read from HBM once instead of three times (two statistics passes of
+// gn_stats_kernel + norm_act_kernel).  The arithmetic -- lane-strided partial sums, wave butterfly, two-pass variance, then
+// norm_act_kernel's per-element expression -- is that of the two kernels, operation for operation: results are bit-identical to
+// bg_groupnorm_stats + bg_im2col(1x1) (tests: program == step by step, where the step-by-step driver calls the two).
+template <int NV, int C4N>           // float4 per lane (n4 = 64 NV per sample); float4 per position (C / 4)
+__global__ __launch_bounds__(256) void gn1_norm_act_kernel(const float* __restrict__ x, void* __restrict__ out, int out_dtype, int S,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           int act, const float* __restrict__ add) {
+    const int lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= S) return;
+    constexpr int N4 = NV * 64;
+    const size_t e0 = (size_t)id * N4 + lane;
+    const float4* __restrict__ base = reinterpret_cast<const float4*>(x) + e0;
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = base[k * 64];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sum += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float inv_n = 1.0f / (float)(N4 * 4);
+    const float mean = wave_sum(sum) * inv_n;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+        var += (a * a + b * b) + (c * c + d * d);
+    }
+    var = wave_sum(var) * inv_n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    // channels of element lane + 64 k: c4 = (lane + 64 k) % C4N -- one (C4N <= 64) or two (C4N = 128) distinct sets per lane
+    constexpr int NSET = C4N > 64 ? C4N / 64 : 1;
+    float4 ga[NSET], be[NSET];
+#pragma unroll
+    for (int q = 0; q < NSET; ++q) {
+        const int c4 = (lane + 64 * q) & (C4N - 1);
+        ga[q] = reinterpret_cast<const float4*>(gamma)[c4];
+        be[q] = reinterpret_cast<const float4*>(beta)[c4];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float4 g4 = ga[k % NSET], b4 = be[k % NSET];
+        float4 w = v[k];
+        w.x = (w.x - mean) * rstd * g4.x + b4.x;
+        w.y = (w.y - mean) * rstd * g4.y + b4.y;
+        w.z = (w.z - mean) * rstd * g4.z + b4.z;
+        w.w = (w.w - mean) * rstd * g4.w + b4.w;
+        w.x = act_apply(w.x, act); w.y = act_apply(w.y, act);
+        w.z = act_apply(w.z, act); w.w = act_apply(w.w, act);
+        if (add) {
+            const float4 ad = reinterpret_cast<const float4*>(add)[e0 + k * 64];
+            w.x += ad.x; w.y += ad.y; w.z += ad.z; w.w += ad.w;
+        }
+        if (out_dtype != BG_F32) reinterpret_cast<uint2*>(out)[e0 + k * 64] = pack4_16(w.x, w.y, w.z, w.w, out_dtype);
+        else reinterpret_cast<float4*>(out)[e0 + k * 64] = w;
+    }
+}
+
+bool gn1_norm_act_supported(int P, int C) {
+    const int n4 = P * (C / 4);
+    return C % 4 == 0 && (n4 == 512 || n4 == 1024) && (C == 128 || C == 256 || C == 512);
+}
+
+// GroupNorm(1, C) + activation (+ add) + cast of [S, P, C] fp32 samples; the caller has checked gn1_norm_act_supported(P, C)
+int gn1_norm_act(const float* x, void* out, int out_dtype, int S, int P, int C, const float* gamma, const float* beta, float eps,
+                 int act, const float* add, hipStream_t s) {
+    const int nv = P * (C / 4) / 64, c4n = C / 4;
+    ProfScope prof(PK_MISC, 0.0, (double)S * P * C * (4.0 + (out_dtype == BG_F32 ? 4.0 : 2.0) + (add ? 4.0 : 0.0)), s);
+    const dim3 grid((S + 3) / 4), block(256);
+#define BG_GN1(NV_, C4N_) hipLaunchKernelGGL((gn1_norm_act_kernel<NV_, C4N_>), grid, block, 0, s, x, out, out_dtype, S, gamma, beta, eps, act, add)
+    if (nv == 8 && c4n == 32) BG_GN1(8, 32);
+    else if (nv == 8 && c4n == 64) BG_GN1(8, 64);
+    else if (nv == 8 && c4n == 128) BG_GN1(8, 128);
+    else if (nv == 16 && c4n == 32) BG_GN1(16, 32);
+    else if (nv == 16 && c4n == 64) BG_GN1(16, 64);
+    else if (nv == 16 && c4n == 128) BG_GN1(16, 128);
+    else {
+        set_error("gn1_norm_act: unsupported shape P=%d C=%d", P, C);
+        return BG_E_SHAPE;
+    }
+#undef BG_GN1
+    return launch_status("gn1_norm_act");
+}
+
 // any C (the 3-channel latent inputs of post_quant_conv / conv_in), no norm, fp32 out
 __global__ __launch_bounds__(256) void im2col_scalar_kernel(Im2colArgs a) {
     const int H = a.Hin << a.up, W = a.Win << a.up, taps = a.kh * a.kw;

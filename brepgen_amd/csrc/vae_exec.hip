@@ -164,11 +164,22 @@ extern "C" int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h
             unsigned char* sc = scratch;
             float* stats = nullptr;
             int rc = 0;
+            // GroupNorm(1, C) over a sample one wave can hold (the 1-D VAE's blocks): statistics + normalisation + activation in ONE pass
+            // wherever the normalised tensor is produced by a 1x1 gather (everything but a materialised im2col over a window)
+            const bool window_gather = o.op == BG_VOP_CONV && !conv_implicit_ok(o, in, S) && (o.kh * o.kw > 1 || o.stride != 1 || o.up != 0 || o.pad_mode != 0);
+            const bool gn1 = o.gn_gamma && o.gn_groups == 1 && !window_gather && g_tune[TUNE_VAE_GN1_FUSED] != 1 &&
+                             gn1_norm_act_supported(P, in.C);
             if (o.gn_gamma) {
                 stats = reinterpret_cast<float*>(sc);
                 sc += al256((size_t)S * o.gn_groups * 2 * 4);
-                if ((rc = bg_groupnorm_stats(src, stats, S, P, in.C, o.gn_groups, o.gn_eps, stream))) return rc;
+                if (!gn1 && (rc = bg_groupnorm_stats(src, stats, S, P, in.C, o.gn_groups, o.gn_eps, stream))) return rc;
             }
+            // act(GroupNorm(src)) (+ add) -> dst_ in `dt`: the one-pass kernel, or the 1x1 gather over the statistics above
+            auto norm_act = [&](void* dst_, int dt, int act, const float* add) -> int {
+                if (gn1) return gn1_norm_act(src, dst_, dt, S, P, in.C, o.gn_gamma, o.gn_beta, o.gn_eps, act, add, (hipStream_t)stream);
+                return bg_im2col(src, dst_, dt, S, in.H, in.W, in.C, 1, 1, 0, 1, 0, 0, in.H, in.W, stats, o.gn_gamma, o.gn_beta,
+                                 o.gn_gamma ? o.gn_groups : 1, act, add, stream);
+            };
             VShape outs;
             switch (o.op) {
                 case BG_VOP_CONV: {
@@ -177,8 +188,7 @@ extern "C" int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h
                     BG_REQUIRE(rows < (1ll << 31), BG_E_SHAPE, "bg_vae_run: chunk of %d samples has %lld output rows", S, rows);
                     if (conv_implicit_ok(o, in, S)) {
                         // normalise + activate + cast once (a 1x1 gather), then the GEMM's loader walks the window
-                        if ((rc = bg_im2col(src, sc, o.w_dtype, S, in.H, in.W, in.C, 1, 1, 0, 1, 0, 0, in.H, in.W, stats, o.gn_gamma,
-                                            o.gn_beta, o.gn_gamma ? o.gn_groups : 1, o.act, nullptr, stream))) return rc;
+                        if ((rc = norm_act(sc, o.w_dtype, o.act, nullptr))) return rc;
                         bg_conv_desc d{};
                         d.x = sc; d.S = S; d.H = in.H; d.W = in.W; d.C = in.C;
                         d.kh = o.kh; d.kw = o.kw; d.up = o.up;
@@ -189,8 +199,10 @@ extern "C" int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h
                         if ((rc = bg_conv_gemm_fwd(&d, stream))) return rc;
                     } else {
                         const int py = o.pad_mode == 0 ? o.kh / 2 : 0, px = o.pad_mode == 0 ? o.kw / 2 : 0;
-                        if ((rc = bg_im2col(src, sc, o.w_dtype, S, in.H, in.W, in.C, o.kh, o.kw, o.up, o.stride, py, px, outs.H, outs.W,
-                                            stats, o.gn_gamma, o.gn_beta, o.gn_gamma ? o.gn_groups : 1, o.act, nullptr, stream))) return rc;
+                        if (gn1) {                                              // (a 1x1 convolution behind GroupNorm(1, C))
+                            if ((rc = norm_act(sc, o.w_dtype, o.act, nullptr))) return rc;
+                        } else if ((rc = bg_im2col(src, sc, o.w_dtype, S, in.H, in.W, in.C, o.kh, o.kw, o.up, o.stride, py, px, outs.H, outs.W,
+                                                   stats, o.gn_gamma, o.gn_beta, o.gn_gamma ? o.gn_groups : 1, o.act, nullptr, stream))) return rc;
                         const int K = o.kh * o.kw * in.C;
                         if ((rc = bg_gemm_bias_act_fwd(sc, K, o.w, o.bias, dst, o.n_out, (int)rows, o.n_out, o.n_pad, K, o.w_dtype, BG_F32,
                                                        BG_ACT_NONE, res, res ? o.n_out : 0, 1, stream))) return rc;
@@ -199,8 +211,7 @@ extern "C" int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h
                 }
                 case BG_VOP_NORM_ACT_ADD:
                     outs = in;
-                    if ((rc = bg_im2col(src, dst, BG_F32, S, in.H, in.W, in.C, 1, 1, 0, 1, 0, 0, in.H, in.W, stats, o.gn_gamma, o.gn_beta,
-                                        o.gn_gamma ? o.gn_groups : 1, o.act, res, stream))) return rc;
+                    if ((rc = norm_act(dst, BG_F32, o.act, res))) return rc;
                     break;
                 case BG_VOP_ATTN: {
                     outs = in;
@@ -210,8 +221,7 @@ extern "C" int bg_vae_run(const bg_vae_op* ops, int n_ops, int n_slots, int in_h
                     float* qkv = reinterpret_cast<float*>(sc);
                     sc += al256(px * 3 * in.C * 4);
                     void* att = sc;
-                    if ((rc = bg_im2col(src, a, o.w_dtype, S, in.H, in.W, in.C, 1, 1, 0, 1, 0, 0, in.H, in.W, stats, o.gn_gamma, o.gn_beta,
-                                        o.gn_gamma ? o.gn_groups : 1, BG_VACT_NONE, nullptr, stream))) return rc;
+                    if ((rc = norm_act(a, o.w_dtype, BG_VACT_NONE, nullptr))) return rc;
                     if ((rc = bg_gemm_bias_act_fwd(a, in.C, o.w, o.bias, qkv, 3 * in.C, (int)px, 3 * in.C, o.n_pad, in.C, o.w_dtype, BG_F32,
                                                    BG_ACT_NONE, nullptr, 0, 1, stream))) return rc;
                     if ((rc = bg_small_attn(qkv, 3 * in.C, att, o.w2_dtype, S, P, in.C, o.heads, o.scale, stream))) return rc;

@@ -465,7 +465,9 @@ int bg_allgather(const void* send, void* recv, size_t bytes_per_rank, void* nccl
  *   key 15  small launches: tile-count threshold of the 64 x 64-tile path (< 0: off)
  *   key 16  FFN1 / FFN2 of layers that carry w_1f / w_2f: 1 = as two GEMM launches instead of the fused launch (bg_ffn_fused_fwd)
  *   keys 17 / 18  measurement aid: low / high 32 bits of a device address that receives s_memtime stamps of the fused FFN launch's
- *           phases (tools/ffn_fused_bench.py stamps); 0 / 0 = off */
+ *           phases (tools/ffn_fused_bench.py stamps); 0 / 0 = off
+ *   key 19  bg_vae_run, GroupNorm(1, C) over samples of 2048 / 4096 values (the 1-D VAE's blocks): 1 = statistics pass + gather as two
+ *           launches (bg_groupnorm_stats, bg_im2col) instead of the one-pass kernel */
 int bg_tune_set(int key, int value);
 
 /* How a 16-bit GEMM launch of `rows` x `n_cols` (n_cols a multiple of 256) is partitioned between the 256 x 256
