@@ -753,7 +753,13 @@ __global__ __launch_bounds__(256, 2) void gemm16_persistent_kernel(GemmArgs g, i
                             if (!PURE && g.out_dtype != BG_F32)
                                 *reinterpret_cast<V4*>(reinterpret_cast<T*>(g.out) + (size_t)grow * g.ldc + gcol) =
                                     E::pack4(v.x, v.y, v.z, v.w);
-                            else
+                            else if (PURE && g.N < BN) {          // narrow convolution: the columns below N only (ldc need not be a multiple of 4)
+                                float* o = reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol;
+                                if (gcol < g.N) o[0] = v.x;
+                                if (gcol + 1 < g.N) o[1] = v.y;
+                                if (gcol + 2 < g.N) o[2] = v.z;
+                                if (gcol + 3 < g.N) o[3] = v.w;
+                            } else
                                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.out) + (size_t)grow * g.ldc + gcol) = v;
                         }
                     }
@@ -829,6 +835,17 @@ static int launch16(const GemmArgs& g, hipStream_t s) {
                                (g.row_map == nullptr || (g.out_lo != nullptr && !g.map_out));   // mapped addends: SPLIT epilogue only
     // (split output / split residual / row statistics / LayerNorm fold are validated in gemm_16bit; both the
     //  persistent and the generic kernel implement them, with bit-identical arithmetic)
+    // narrow implicit-GEMM convolution (the VAEs' conv_out: 3 channels): ONE 128-column tile per row panel over weights zero-padded
+    // to 128 rows; the epilogue stores only the columns below N (scalar stores: ldc = N)
+    const bool narrow_conv = g.cv_C > 0 && g.N < g.N_pad && g.N_pad == 128 && nt >= 64 && g.out_dtype == BG_F32 && !g.add && !g.add2 &&
+                             g.act == BG_ACT_NONE && g.add_div == 1 && !g.out_lo && !g.stats_in && !g.row_map && g.bias;
+    if (narrow_conv) {
+        double fl, by;
+        gemm_cost(g, rows_all, fl, by);
+        ProfScope prof(PK_GEMM_BF16_128, fl, by, s);
+        hipLaunchKernelGGL((gemm16_persistent_kernel<F16, P_GENERAL, true, true>), dim3(nt < 512 ? (nt & ~7) : 512), dim3(256), 0, s, g, m128);
+        return launch_status("gemm16(narrow conv)");
+    }
     if (g.cv_C > 0 && (!persistent_ok || g.out_dtype != BG_F32 || g.out_lo || g.stats_in)) {
         set_error("gemm_16bit: the implicit-GEMM convolution needs the persistent kernel (N %% 128 == 0, >= 64 tiles, fp32 output)");
         return BG_E_SHAPE;

@@ -163,13 +163,15 @@ extern "C" int bg_conv_gemm_fwd(const bg_conv_desc* d, bg_stream_t stream) {
     BG_REQUIRE(d->S > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->N > 0, BG_E_SHAPE, "bg_conv_gemm_fwd: empty shape");
     const int Ho = d->H << d->up, Wo = d->W << d->up;
     const int lw = ilog2_exact(Wo), lh = ilog2_exact(Ho), ls = (d->C % 64 == 0) ? ilog2_exact(d->C / 64) : -1;
-    BG_REQUIRE(lw >= 0 && lh >= 0 && ls >= 0 && (d->kh & 1) && (d->kw & 1) && d->up >= 0 && d->up <= 1 && d->N % 128 == 0, BG_E_SHAPE,
-               "bg_conv_gemm_fwd: needs power-of-two output grid, C / 64 a power of two, odd window, N %% 128 == 0 "
-               "(H=%d W=%d up=%d C=%d k=%dx%d N=%d)", d->H, d->W, d->up, d->C, d->kh, d->kw, d->N);
+    const bool narrow = d->N < 128;                                // w / bias zero-padded to 128 rows by the caller, no residual
+    BG_REQUIRE(lw >= 0 && lh >= 0 && ls >= 0 && (d->kh & 1) && (d->kw & 1) && d->up >= 0 && d->up <= 1 &&
+                   (d->N % 128 == 0 || (narrow && d->add == nullptr && d->bias != nullptr)), BG_E_SHAPE,
+               "bg_conv_gemm_fwd: needs power-of-two output grid, C / 64 a power of two, odd window, N %% 128 == 0 -- or N < 128 with "
+               "w and bias padded to 128 rows and no residual (H=%d W=%d up=%d C=%d k=%dx%d N=%d)", d->H, d->W, d->up, d->C, d->kh, d->kw, d->N);
     BG_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->zero_page & 127) == 0, BG_E_ALIGN, "bg_conv_gemm_fwd: alignment");
     const long long rows = (long long)d->S * Ho * Wo;
     BG_REQUIRE(rows < (1ll << 31), BG_E_SHAPE, "bg_conv_gemm_fwd: too many output pixels for one call (%lld)", rows);
-    bg::GemmArgs g{d->x, d->C, d->w, d->bias, d->out, d->ldc, (int)rows, d->N, d->N, d->kh * d->kw * d->C, BG_F32, BG_ACT_NONE,
+    bg::GemmArgs g{d->x, d->C, d->w, d->bias, d->out, d->ldc, (int)rows, d->N, narrow ? 128 : d->N, d->kh * d->kw * d->C, BG_F32, BG_ACT_NONE,
                    d->add, d->ld_add, 1};
     g.cv_C = d->C; g.cv_H = d->H; g.cv_W = d->W; g.cv_kh = d->kh; g.cv_kw = d->kw; g.cv_up = d->up;
     g.cv_wo_log2 = lw; g.cv_ho_log2 = lh; g.cv_spt_log2 = ls; g.cv_zero = d->zero_page;

@@ -426,22 +426,33 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict
 // the same with the sample's q|k|v rows staged in LDS by coalesced 16-byte loads first (the edge VAE: 4 tokens x 1536
 // floats = 24 KiB per sample; the strided scalar reads of the kernel above ran at a quarter of the HBM rate).  Same
 // fmaf chains in the same order: bit-identical results.
+// LDS image: column c of a row lives at c + 4 * (c / d) (4 floats of padding per head-sized chunk), rows `wp` floats apart with
+// wp % 64 == 16: in the score phase the 64 lanes of a wave read q (and k) of 4 heads x 4 rows at the SAME offset t -- unpadded
+// (row stride 1536, head stride 32) those 16 addresses fall on two of the 64 banks, an 8-way conflict on every one of the 2 x 32
+// reads of a dot product, and the launch ran at 2.5 TB/s bound by the LDS pipe; padded they fall on 16 different banks.
+__device__ __forceinline__ int sa_col(int c, int d) { return c + 4 * (c / d); }
+__host__ __device__ inline int sa_row_stride(int C, int d) {
+    int wp = 3 * C + 4 * (3 * C / d);
+    while ((wp & 63) != 16) wp += 4;
+    return wp;
+}
+
 __global__ __launch_bounds__(256) void small_attn_lds_kernel(const float* __restrict__ qkv, int ld, void* __restrict__ out,
                                                              int out_dtype, int T, int C, int nh, float scale) {
-    extern __shared__ float sm[];                           // [T][3C] rows | [nh][T][T] scores
+    extern __shared__ float sm[];                           // [T][wp] padded rows | [nh][T][T] scores
     const int s = blockIdx.x, d = C / nh, n_sc = nh * T * T, w4 = (3 * C) >> 2;
-    float* sc = sm + (size_t)T * 3 * C;
+    const int wp = sa_row_stride(C, d);
+    float* sc = sm + (size_t)T * wp;
     const float* base = qkv + (size_t)s * T * ld;
     for (int e = threadIdx.x; e < T * w4; e += blockDim.x) {
         const int row = e / w4, c4 = e - row * w4;
-        reinterpret_cast<float4*>(sm)[e] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + c4 * 4);
+        *reinterpret_cast<float4*>(sm + row * wp + sa_col(c4 * 4, d)) = *reinterpret_cast<const float4*>(base + (size_t)row * ld + c4 * 4);
     }
     __syncthreads();
-    const int W = 3 * C;
     for (int e = threadIdx.x; e < n_sc; e += blockDim.x) {
         const int j = e % T, i = (e / T) % T, hh = e / (T * T);
-        const float* q = sm + i * W + hh * d;
-        const float* k = sm + j * W + C + hh * d;
+        const float* q = sm + i * wp + sa_col(hh * d, d);
+        const float* k = sm + j * wp + sa_col(C + hh * d, d);
         float acc = 0.f;
         for (int t = 0; t < d; ++t) acc = fmaf(q[t], k[t], acc);
         sc[e] = acc * scale;
@@ -460,8 +471,9 @@ __global__ __launch_bounds__(256) void small_attn_lds_kernel(const float* __rest
     for (int e = threadIdx.x; e < T * C; e += blockDim.x) {
         const int col = e % C, i = e / C, hh = col / d;
         const float* p = sc + ((size_t)hh * T + i) * T;
+        const int vc = sa_col(2 * C + col, d);
         float acc = 0.f;
-        for (int j = 0; j < T; ++j) acc = fmaf(p[j], sm[j * W + 2 * C + col], acc);
+        for (int j = 0; j < T; ++j) acc = fmaf(p[j], sm[j * wp + vc], acc);
         const size_t o = ((size_t)s * T + i) * C + col;
         if (out_dtype == BG_BF16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)acc;
         else if (out_dtype == BG_F16) reinterpret_cast<_Float16*>(out)[o] = (_Float16)acc;
@@ -549,7 +561,8 @@ extern "C" int bg_small_attn(const float* qkv, int ld, void* out, int out_dtype,
     BG_REQUIRE(nh * T * T <= 8192, BG_E_SHAPE, "bg_small_attn: nh*T*T = %d exceeds the LDS score buffer", nh * T * T);
     BG_REQUIRE(out_dtype == BG_F32 || out_dtype == BG_BF16 || out_dtype == BG_F16, BG_E_DTYPE, "bg_small_attn: out dtype %d", out_dtype);
     bg::ProfScope prof(bg::PK_MISC, 4.0 * S * (double)T * T * C, 16.0 * S * (double)T * C, (hipStream_t)stream);
-    const size_t staged = ((size_t)T * 3 * C + (size_t)nh * T * T) * sizeof(float);
+    const int d = C / nh;
+    const size_t staged = d % 4 == 0 ? ((size_t)T * bg::sa_row_stride(C, d) + (size_t)nh * T * T) * sizeof(float) : ~(size_t)0;
     if (staged <= 40 * 1024 && C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)qkv & 15) == 0)        // >= 4 workgroups per CU
         hipLaunchKernelGGL(bg::small_attn_lds_kernel, dim3(S), dim3(256), staged, (hipStream_t)stream, qkv, ld, out, out_dtype, T, C,
                            nh, scale);

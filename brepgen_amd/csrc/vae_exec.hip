@@ -25,9 +25,11 @@ static bool conv_implicit_ok(const bg_vae_op& o, const VShape& in, int S) {
     if (o.w_dtype == BG_F32 || o.kh * o.kw <= 1 || o.stride != 1 || o.pad_mode != 0) return false;
     const int Ho = in.H << o.up, Wo = in.W << o.up;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (in.C % 64 != 0 || !pow2(in.C / 64) || !pow2(Ho) || !pow2(Wo) || o.n_out % 128 != 0 || o.n_pad != o.n_out) return false;
+    // whole 128-column tiles, or a NARROW output (conv_out: 3 channels) whose weights the module padded to one 128-row tile
+    const bool wide = o.n_out % 128 == 0 && o.n_pad == o.n_out, narrow = o.n_out < 128 && o.n_pad == 128 && o.res < 0;
+    if (in.C % 64 != 0 || !pow2(in.C / 64) || !pow2(Ho) || !pow2(Wo) || !(wide || narrow)) return false;
     const long long rows = (long long)S * Ho * Wo;
-    return rows < (1ll << 31) && ((rows + 127) / 128) * (o.n_out / 128) >= 64;
+    return rows < (1ll << 31) && ((rows + 127) / 128) * (o.n_pad / 128) >= 64;
 }
 
 static void conv_out_shape(const bg_vae_op& o, const VShape& in, VShape& out) {

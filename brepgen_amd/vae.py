@@ -336,12 +336,12 @@ class _HipVAE(nn.Module):
 
     # ---- packing ----
     @staticmethod
-    def _pack_gemm(weight2d, bias, dt):
+    def _pack_gemm(weight2d, bias, dt, pad16=64):
         n, k = weight2d.shape
         p = _Packed()
         use = dt if (dt == torch.float32 or k % 64 == 0) else torch.float32
         w = weight2d.detach().to(torch.float32)
-        pad = 1 if use == torch.float32 else 64
+        pad = 1 if use == torch.float32 else pad16
         if n % pad:
             w = torch.cat([w, w.new_zeros((-n) % pad, k)])
         p.w = w.to(use).contiguous()
@@ -351,13 +351,16 @@ class _HipVAE(nn.Module):
         p.b, p.n, p.k, p.dtype = b.contiguous(), n, k, use
         return p
 
-    def _pack_conv(self, conv, dt):
+    def _pack_conv(self, conv, dt, pad16=64):
+        """pad16: rows the 16-bit weight matrix is zero-padded to a multiple of.  128 for a NARROW windowed convolution (conv_out:
+        3 output channels): the implicit GEMM then takes it as one 128-column tile that stores only the real columns, instead of
+        materialising the 9-fold / 3-fold im2col matrix of the largest activation of the pass for the generic kernel."""
         w = conv.weight.detach()
         if w.dim() == 3:                               # Conv1d [Cout, Cin, k] -> [Cout, k*Cin] (tap-major)
             w2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)
         else:                                          # Conv2d [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
             w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
-        return self._pack_gemm(w2, conv.bias, dt)
+        return self._pack_gemm(w2, conv.bias, dt, pad16)
 
     # ---- primitive steps on channels-last fp32 tensors [S, H, W, C] ----
     def _pack_resnet2d(self, P, name, r, dt):
@@ -409,7 +412,7 @@ class AutoencoderKLFastDecode(_HipVAE):
                 self._pack_resnet2d(P, f"u{bi}r{ri}", r, dt)
             if hasattr(blk, "upsamplers"):
                 P[f"u{bi}up"] = self._pack_conv(blk.upsamplers[0].conv, dt)
-        P["out"] = self._pack_conv(d.conv_out, dt)
+        P["out"] = self._pack_conv(d.conv_out, dt, pad16=128)
         self._packs[dt] = P
         return P
 
@@ -487,7 +490,7 @@ class AutoencoderKL1DFastDecode(_HipVAE):
         for bi, blk in enumerate(d.up_blocks):
             for ri, r in enumerate(blk.resnets):
                 self._pack_resconv(P, f"u{bi}r{ri}", r, dt)
-        P["out"] = self._pack_conv(d.conv_out, dt)
+        P["out"] = self._pack_conv(d.conv_out, dt, pad16=128)
         self._packs[dt] = P
         return P
 
@@ -616,7 +619,7 @@ class AutoencoderKLFastEncode(_HipVAE):
         self._pack_resnet2d(P, "m0", e.mid_block.resnets[0], dt)
         self._pack_resnet2d(P, "m1", e.mid_block.resnets[1], dt)
         self._pack_attn2d(P, "ma", e.mid_block.attentions[0], dt)
-        P["out"] = self._pack_conv(e.conv_out, dt)
+        P["out"] = self._pack_conv(e.conv_out, dt, pad16=128)
         P["q"] = self._pack_conv(self.quant_conv, dt)
         self._packs[dt] = P
         return P
@@ -686,7 +689,7 @@ class AutoencoderKL1DFastEncode(_HipVAE):
         for i in range(6):
             self._pack_resconv(P, f"m{i}", e.mid_block.resnets[i], dt)
             self._pack_attn1d(P, f"a{i}", e.mid_block.attentions[i], dt)
-        P["out"] = self._pack_conv(e.conv_out, dt)
+        P["out"] = self._pack_conv(e.conv_out, dt, pad16=128)
         P["q"] = self._pack_conv(self.quant_conv, dt)
         self._packs[dt] = P
         return P

@@ -101,7 +101,9 @@ int bg_gemm_ex_fwd(const bg_gemm_desc* d, bg_stream_t stream);
  *   'same' convolution, stride 1, window kh x kw (odd), on the nearest-upsampled grid (H << up, W << up) = (Ho, Wo), both
  *         powers of two; zero padding outside (padded taps read zero_page: one pixel = 2 * C bytes of zeros on the device)
  *   w     [N, kh*kw*C] 16-bit, tap-major (tap = ky*kw + kx, then channel), N % 128 == 0;  bias fp32 [N] or NULL
- *   out   fp32 [S*Ho*Wo, N] (row stride ldc) = conv + bias (+ add: fp32 residual rows, row stride ld_add)
+ *         -- or a NARROW output, N < 128 (the decoders' conv_out, network.py:786-858 / 948-1040: 3 channels): w [128, kh*kw*C] and
+ *         bias [128] zero-padded by the caller, no residual; one 128-column tile per row panel, only the N real columns stored
+ *   out   fp32 [S*Ho*Wo, N] (row stride ldc >= N) = conv + bias (+ add: fp32 residual rows, row stride ld_add)
  * Needs at least 64 output tiles of 128 x 128 (it runs on the persistent kernel); smaller problems: im2col + GEMM. */
 typedef struct {
     const void* x; int S, H, W, C;

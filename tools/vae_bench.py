@@ -21,6 +21,8 @@ edge = bga.AutoencoderKL1DFastDecode(**EDGE_VAE_CFG).cuda().eval()
 surf.compute_dtype = edge.compute_dtype = torch.bfloat16
 F_, G_ = (15360, 460800) if len(sys.argv) < 3 else (int(sys.argv[1]), int(sys.argv[2]))
 ONLY = sys.argv[3].split(",") if len(sys.argv) > 3 else None      # e.g. "one_call_program" for a rocprofv3 run
+if len(sys.argv) > 4 and sys.argv[4] == "serial":                  # one stream, no concurrent halves: kernel durations a profiler can add up
+    surf.two_streams = edge.two_streams = False
 zs = torch.randn(F_, 48, device="cuda")
 ze = torch.randn(G_, 12, device="cuda")
 FLOP = F_ * 9.69e9 + G_ * 0.416e9
