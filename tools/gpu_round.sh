@@ -53,5 +53,21 @@ if [[ $WHAT == all || $WHAT == attnpmc ]]; then
   python tools/attn_pmc_summary.py r06 > $O/attn_pmc_summary.log 2>&1
   cp profiles/r06/attn_pmc_per_launch_shape.json $O/ 2>/dev/null
 fi
+if [[ $WHAT == all || $WHAT == vaeprof ]]; then
+  # VAE decode of configs[2]'s output on ONE stream (no concurrent halves: kernel durations add up to the pass)
+  export TMPDIR=/tmp
+  cd /tmp
+  rm -rf $O/vae_prof
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/vae_prof -o vae -- python $R/tools/vae_bench.py 15360 460800 one_call_program serial > $O/vae_prof.log 2>&1
+  echo "vaeprof rc=$?" >> $O/vae_prof.log
+  rm -f $O/vae_prof/*trace.csv
+  cd $R
+  timeout 300 python tools/vae_concurrent_bench.py > $O/vae_concurrent_bench.log 2>&1
+fi
+if [[ $WHAT == driver ]]; then
+  # the command the driver runs at round end
+  timeout 1700 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1; echo "bench rc=$?" >> $O/bench_driver_cmd.log
+  tail -2 $O/bench_driver_cmd.log | cut -c1-260
+fi
 du -ah $O | sort -h | tail -30 > $O/listing.txt 2>&1
 find $O -type f -size +16M -print -delete >> $O/listing.txt 2>&1
