@@ -253,7 +253,7 @@ constexpr int AL_MAX_N = 4096;       // longest sequence the long kernel stages 
 template <bool F16, bool MASKED>      // MASKED: a key-padding mask is given (dense execution); otherwise only keys >= N are dead
 __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restrict__ qkv_, const uint8_t* __restrict__ key_pad,
                                                              void* __restrict__ out_, int B, int N, int nqb,
-                                                             const int* __restrict__ offsets) {
+                                                             const int* __restrict__ offsets, int eighths) {
     using E = AElem<F16>;
     using T = typename E::T;
     using V8 = typename E::V8;
@@ -273,7 +273,12 @@ __global__ __launch_bounds__(256, 3) void attn16_long_kernel(const void* __restr
     // that unit's K / V in its L2 -- and the units go round-robin over the XCDs, so that every XCD gets 1.5 heads of EVERY sample.
     // (Until round 6 each XCD walked a contiguous eighth of the batch: with ragged samples the XCDs' shares of sum n_b^2 differed
     // by +- 15 % at the bench's edge batches and the launch lasted as long as the heaviest eighth.)
-    const int unit = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7), qb = (int)(blockIdx.x >> 3) % nqb;
+    int unit = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7);
+    const int qb = (int)(blockIdx.x >> 3) % nqb;
+    if (eighths) {                                       // (bg_tune key 20 = 1: the walk of rounds 2-5, for the in-process A/B)
+        const int upx = (int)(gridDim.x >> 3) / nqb;     // units per XCD of the padded grid
+        unit = (int)(blockIdx.x & 7) * upx + (int)(blockIdx.x >> 3) / nqb;
+    }
     if (unit >= B * BG_N_HEAD) return;                   // (grid padded to whole rounds of 8 units)
     const int head = unit % BG_N_HEAD, b = unit / BG_N_HEAD;
     size_t row_base = (size_t)b * N;
@@ -572,10 +577,11 @@ int attention(const void* qkv, const uint8_t* key_pad, void* out, int B, int N, 
             const int nqb = (N + 127) / 128;
             const dim3 grid((unsigned)(nqb * 8 * ((B * BG_N_HEAD + 7) / 8)));
             const bool masked = key_pad != nullptr && offsets == nullptr;
-            if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
-            else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
-            else if (masked) hipLaunchKernelGGL((attn16_long_kernel<false, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
-            else hipLaunchKernelGGL((attn16_long_kernel<false, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets);
+            const int eighths = g_tune[TUNE_ATTN_WALK] == 1;
+            if (f16 && masked) hipLaunchKernelGGL((attn16_long_kernel<true, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, eighths);
+            else if (f16) hipLaunchKernelGGL((attn16_long_kernel<true, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, eighths);
+            else if (masked) hipLaunchKernelGGL((attn16_long_kernel<false, true>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, eighths);
+            else hipLaunchKernelGGL((attn16_long_kernel<false, false>), grid, dim3(256), 0, s, qkv, key_pad, out, B, N, nqb, offsets, eighths);
         }
         return launch_status("attn16");
     }

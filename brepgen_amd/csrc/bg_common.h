@@ -36,7 +36,7 @@ struct ProfScope {      // records a hipEvent pair around one launch when profil
 // ---- tuning knobs (bg_tune_set; defaults are the shipped configuration) ----
 // (8: phase-group delay of split-residual launches on the 256 x 256 kernel; 10: 256-kernel mode; 12: split-residual kernel choice;
 //  13: 1 = QKV and attention as two launches even where the fused kernel (qkv_attn.hip) applies; 14: tile walk of that kernel (1 = plain, 2 = XCD-pinned head halves, 0 = by size); 15: small-launch threshold; 16: 1 = FFN1 and FFN2 as two launches even where w_1f / w_2f are given -- each backs a bit-equality test, see gemm_16bit.hip launch16)
-enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_VAE_GN1_FUSED = 19, TUNE_COUNT = 20 };
+enum TuneKey { TUNE_GEMM_STAGGER = 8, TUNE_P256_MODE = 10, TUNE_SPLIT_PIPE = 12, TUNE_QKV_ATTN = 13, TUNE_QKV_WALK = 14, TUNE_SMALL_TILES = 15, TUNE_FFN_FUSED = 16, TUNE_DEBUG_PTR_LO = 17, TUNE_DEBUG_PTR_HI = 18, TUNE_VAE_GN1_FUSED = 19, TUNE_ATTN_WALK = 20, TUNE_COUNT = 21 };
 extern int g_tune[TUNE_COUNT];
 
 // ---- vector types -----------------------------------------------------------------------------

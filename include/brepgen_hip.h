@@ -469,7 +469,10 @@ int bg_allgather(const void* send, void* recv, size_t bytes_per_rank, void* nccl
  *   keys 17 / 18  measurement aid: low / high 32 bits of a device address that receives s_memtime stamps of the fused FFN launch's
  *           phases (tools/ffn_fused_bench.py stamps); 0 / 0 = off
  *   key 19  bg_vae_run, GroupNorm(1, C) over samples of 2048 / 4096 values (the 1-D VAE's blocks): 1 = statistics pass + gather as two
- *           launches (bg_groupnorm_stats, bg_im2col) instead of the one-pass kernel */
+ *           launches (bg_groupnorm_stats, bg_im2col) instead of the one-pass kernel
+ *   key 20  long-sequence attention: 1 = each XCD walks a contiguous eighth of the (sample, head) units (rounds 2-5) instead of the
+ *           units going round-robin over the XCDs (ragged batches: the eighths' shares of sum n_b^2 differ, the launch lasts as long
+ *           as the heaviest) */
 int bg_tune_set(int key, int value);
 
 /* How a 16-bit GEMM launch of `rows` x `n_cols` (n_cols a multiple of 256) is partitioned between the 256 x 256

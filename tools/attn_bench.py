@@ -46,8 +46,13 @@ for B, N, dt in [(256, 1800, torch.bfloat16), (64, 4000, torch.bfloat16), (128, 
     for name, (kp, of, pairs) in cases.items():
         res = {}
         for rnd in range(2):
-            us = timed(lambda: call(kp, of), 5 if N > 64 else 20)
-            res.setdefault("new", []).append(us)
+            # long kernel: (sample, head) units round-robin over the XCDs (the library's walk) vs a contiguous eighth per XCD (rounds 2-5;
+            # bg_tune key 20), alternated in this process
+            for name_, key in (("round_robin", 0), ("eighths", 1)) if N > 64 else (("new", 0),):
+                lib.bg_tune_set(20, key)
+                us = timed(lambda: call(kp, of), 5 if N > 64 else 20)
+                res.setdefault(name_, []).append(us)
+            lib.bg_tune_set(20, 0)
         row = {"B": B, "N": N, "dtype": str(dt)[6:], "case": name,
                **{k: {"us": round(min(v), 1), "tflops_executed": round(4.0 * 12 * 64 * pairs / min(v) / 1e6, 1)} for k, v in res.items()}}
         rows.append(row)
