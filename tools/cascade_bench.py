@@ -70,13 +70,28 @@ def run(B=256, datalike=False, graphs=False):
         smp.dedup_surfaces, smp.dedup_edges = real_s, real_e
     stages = {k: round(v, 3) for k, v in stages.items()}
     finite = all(bool(torch.isfinite(v).all()) for v in dec.values() if v.is_floating_point())
+    # executed FLOPs of the four loops on the masks this run produced (F(n) per sample and evaluation; the
+    # face-position net runs 158 PNDM steps on S faces and 250 DDPM steps on 2 S, no mask; the edge-position net on every edge slot of
+    # a valid face; the per-face conditioning embeds of the edge nets: 2.44 MFLOP per face) -- the unit's own roofline figure
+    F = lambda n, c: n * (12 * 7_864_320 + c) + 36_864 * n * n
+    nf = (~lat["surfMask"]).sum(1).double().cpu()
+    ne = (~lat["edgeM"]).sum((1, 2)).double().cpu()
+    fl = {"surfPos": B * (158 * F(S, 2.38e6) + 250 * F(2 * S, 2.38e6)),
+          "surfZ": 209 * float(sum(F(float(n), 3.70e6 - 2.44e6) for n in nf)) + 209 * B * 2 * S * 2.44e6,
+          "edgePos": 408 * (float(sum(F(float(n) * E, 2.38e6) for n in nf)) + B * 2 * S * 2.44e6),
+          "edgeZV": 209 * (float(sum(F(float(n), 4.78e6) for n in ne)) + B * 2 * S * 2.44e6)}
+    roof = {k: {"executed_tflop": round(v / 1e12, 1), "executed_tflops": round(v / 1e12 / stages[k], 1),
+                "frac_of_mfma_peak": round(v / 1e12 / stages[k] / 2500.0, 4)} for k, v in fl.items() if stages.get(k)}
+    roof["cascade"] = {"executed_tflop": round(sum(fl.values()) / 1e12, 1), "executed_tflops": round(sum(fl.values()) / 1e12 / t_cas, 1),
+                       "frac_of_mfma_peak": round(sum(fl.values()) / 1e12 / t_cas / 2500.0, 4), "bound": "mfma",
+                       "peak": "2500 TFLOP/s dense bf16"}
     return {"workload": f"DeepCAD cascade, batch {B}, {S}x2 faces x {E} edges, bf16, random-init weights"
                         + (", SYNTHETIC data-like validity masks" if datalike else ""),
             "graphs": graphs, "stage_s": stages, "vae_decode_s": round(t_dec, 3), "cascade_s": round(t_cas, 3),
             "total_s": round(t_cas + t_dec, 3), "samples_per_s": round(B / (t_cas + t_dec), 2),
             "valid_faces_mean": round(float((~lat["surfMask"]).sum(1).float().mean()), 2),
             "valid_edges_mean_per_sample": round(float((~lat["edgeM"]).sum((1, 2)).float().mean()), 1),
-            "finite": finite}
+            "roofline": roof, "finite": finite}
 
 
 if __name__ == "__main__":

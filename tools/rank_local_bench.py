@@ -54,6 +54,23 @@ def run(name, k=None):
            "valid_faces_mean": round(float((~lat["surfMask"]).sum(1).float().mean()), 2),
            "valid_edges_mean_per_sample": round(float((~lat["edgeM"]).sum((1, 2)).float().mean()), 1),
            "finite": all(bool(torch.isfinite(v).all()) for v in lat.values() if v.is_floating_point())}
+    if k is None:
+        # executed FLOPs of the full loops on the masks this run produced (F(n) per sample and evaluation; with
+        # guidance every evaluation runs conditional + unconditional rows): the unit's own roofline figure
+        F = lambda n, c: n * (12 * 7_864_320 + c) + 36_864 * n * n
+        rows = 2 if cf else 1
+        nf = (~lat["surfMask"]).sum(1).double().cpu()
+        ne = (~lat["edgeM"]).sum((1, 2)).double().cpu()
+        S2 = S if cf else 2 * S                                       # (the late doubling of sample.py:140-142 happens without guidance only)
+        fl = {"surfPos": rows * B * (158 * F(S, 2.38e6) + 250 * F(S2, 2.38e6)),
+              "surfZ": rows * 209 * (float(sum(F(float(n), 3.70e6 - 2.44e6) for n in nf)) + B * S2 * 2.44e6),
+              "edgePos": rows * 408 * (float(sum(F(float(n) * E, 2.38e6) for n in nf)) + B * S2 * 2.44e6),
+              "edgeZV": rows * 209 * (float(sum(F(float(n), 4.78e6) for n in ne)) + B * S2 * 2.44e6)}
+        out["roofline"] = {s: {"executed_tflop": round(v / 1e12, 1), "executed_tflops": round(v / 1e12 / stages[s], 1),
+                               "frac_of_mfma_peak": round(v / 1e12 / stages[s] / 2500.0, 4)} for s, v in fl.items()}
+        out["roofline"]["loops"] = {"executed_tflop": round(sum(fl.values()) / 1e12, 1), "executed_tflops": round(sum(fl.values()) / 1e12 / total, 1),
+                                    "frac_of_mfma_peak": round(sum(fl.values()) / 1e12 / total / 2500.0, 4), "bound": "mfma",
+                                    "peak": "2500 TFLOP/s dense " + ("fp16" if dt == torch.float16 else "bf16")}
     if k is not None:
         # A K-iteration run does NOT reproduce the full loops' token counts: after a few iterations the de-duplication between the
         # stages removes only the exact copies of the late doubling, and every edge slot stays valid, whereas the full loops (even
