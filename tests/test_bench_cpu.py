@@ -38,3 +38,13 @@ def test_more_gpus_than_the_node_has_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=_env(), timeout=300)
     assert r.returncode != 0 and "exposes" in (r.stderr + r.stdout)
+
+
+def test_every_tool_script_compiles():
+    """tools/*.py run on the GPU box only; a syntax error there costs a gpurun call -- compile them all here."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(files) >= 20
+    for f in files:
+        compile(open(f).read(), f, "exec")
